@@ -1,0 +1,424 @@
+"""Host-side mirror of the reference's public interface for the RAM path, over the C ABI.
+
+Names, argument meaning and error behaviour follow /root/reference/src:
+  Parameters              parameters.rs:147-287
+  EvaluationKeysPrepared  keys.rs:27-71
+  Address                 address.rs:21-119
+  Ram                     ram.rs:25-294  (read :172, read_prepare_write :196, write :226)
+The reference panics on misuse (assert!); here every failing call raises FheRamError carrying
+the C-ABI status and the reference's message.
+
+All ciphertext data crosses this boundary as numpy int64 arrays in Poulpy's host layouts
+(include/fheram.h).  There is NO CPU implementation behind these classes: if the HIP library is
+missing or no GPU is present, construction fails loudly.
+"""
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .base import Base2D, get_base_2d
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+I64P = C.POINTER(C.c_int64)
+
+STATUS = {0: "OK", 1: "INVALID_ARG", 2: "STATE", 3: "UNINITIALIZED", 4: "KEYS", 5: "UNSUPPORTED", 6: "RANGE", 7: "DEVICE"}
+
+
+class FheRamError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"fheram status {code} ({STATUS.get(code, '?')}): {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class _CParams(C.Structure):
+    _fields_ = [("log_n", C.c_uint32), ("base2k", C.c_uint32), ("rank", C.c_uint32), ("k_glwe_pt", C.c_uint32),
+                ("k_glwe_ct", C.c_uint32), ("k_ggsw_addr", C.c_uint32), ("k_evk_trace", C.c_uint32),
+                ("k_evk_ggsw_inv", C.c_uint32), ("word_size", C.c_uint32), ("n_decomp", C.c_uint32),
+                ("decomp_n", C.c_uint8 * 16), ("max_addr", C.c_uint64)]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libfheram.so")
+
+
+# every symbol include/fheram.h declares: (name, restype, argtypes)
+_SYMBOLS = [
+    ("fheram_params_default", C.c_int, [C.POINTER(_CParams)]),
+    ("fheram_ctx_create", C.c_int, [C.POINTER(_CParams), C.c_int, C.POINTER(C.c_void_p)]),
+    ("fheram_ctx_destroy", None, [C.c_void_p]),
+    ("fheram_last_error", C.c_char_p, [C.c_void_p]),
+    ("fheram_glwe_len", C.c_size_t, [C.c_void_p]),
+    ("fheram_ggsw_len", C.c_size_t, [C.c_void_p]),
+    ("fheram_atk_len", C.c_size_t, [C.c_void_p]),
+    ("fheram_evk_inv_len", C.c_size_t, [C.c_void_p]),
+    ("fheram_rows", C.c_size_t, [C.c_void_p]),
+    ("fheram_n_digits", C.c_int, [C.c_void_p]),
+    ("fheram_n_coordinates", C.c_int, [C.c_void_p]),
+    ("fheram_keys_load", C.c_int, [C.c_void_p, I64P, C.c_int, C.POINTER(I64P), I64P, C.c_int64, I64P]),
+    ("fheram_ram_upload", C.c_int, [C.c_void_p, I64P]),
+    ("fheram_ram_download", C.c_int, [C.c_void_p, I64P]),
+    ("fheram_ram_tree_download", C.c_int, [C.c_void_p, C.c_int, I64P]),
+    ("fheram_ram_state", C.c_int, [C.c_void_p]),
+    ("fheram_address_create", C.c_int, [C.c_void_p, C.POINTER(I64P), C.c_int, C.POINTER(C.c_void_p)]),
+    ("fheram_address_destroy", None, [C.c_void_p]),
+    ("fheram_read", C.c_int, [C.c_void_p, C.c_void_p, I64P]),
+    ("fheram_read_prepare_write", C.c_int, [C.c_void_p, C.c_void_p, I64P]),
+    ("fheram_write", C.c_int, [C.c_void_p, I64P, C.c_int, C.c_void_p]),
+    ("fheram_word_stage", C.c_int, [C.c_void_p, I64P, C.c_int]),
+    ("fheram_result_download", C.c_int, [C.c_void_p, I64P]),
+    ("fheram_sync", C.c_int, [C.c_void_p]),
+    ("fheram_glwe_external_product", C.c_int, [C.c_void_p, I64P, C.c_int, I64P, I64P]),
+    ("fheram_glwe_automorphism", C.c_int, [C.c_void_p, C.c_int, C.c_int64, I64P, C.c_int, I64P]),
+    ("fheram_glwe_trace", C.c_int, [C.c_void_p, C.c_int, C.c_int, I64P, C.c_int, I64P]),
+    ("fheram_glwe_pack", C.c_int, [C.c_void_p, I64P, C.c_int, I64P]),
+    ("fheram_ggsw_automorphism_inv", C.c_int, [C.c_void_p, I64P, I64P]),
+    ("fheram_timer_begin", C.c_int, [C.c_void_p]),
+    ("fheram_timer_end", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    ("fheram_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("fheram_profile_get", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    ("fheram_profile_reset", C.c_int, [C.c_void_p]),
+    ("fheram_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+]
+
+
+def exported_symbols() -> List[str]:
+    return [s[0] for s in _SYMBOLS]
+
+
+def library():
+    """Load the HIP C-ABI library.  Fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise FheRamError(7, f"HIP extension missing: {path} not built (run __graft_entry__.build()); "
+                                 "there is no CPU fallback")
+        L = C.CDLL(path)
+        for name, res, args in _SYMBOLS:
+            f = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.int64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(I64P)
+
+
+def _i64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def galois_elements(log_n: int = 12) -> List[int]:
+    """GLWE::trace_galois_elements (keys.rs:39,158): -1, then 5^(2^(i-1)) mod 2N."""
+    two_n = 2 << log_n
+    return [-1] + [pow(5, 1 << (i - 1), two_n) for i in range(1, log_n)]
+
+
+class Parameters:
+    """parameters.rs:147-176.  Defaults are the source constants (parameters.rs:11-21)."""
+
+    def __init__(self, max_addr: int = 1 << 14, decomp_n: Sequence[int] = (3, 3, 3, 3), word_size: int = 4):
+        self.log_n, self._base2k, self._rank = 12, 17, 1
+        self._k_glwe_pt, self._k_glwe_ct, self._k_ggsw_addr = 3, 51, 68
+        self._k_evk_trace, self._k_evk_ggsw_inv = 68, 85
+        assert sum(decomp_n) == self.log_n  # parameters.rs:168
+        self._max_addr, self._decomp_n, self._word_size = int(max_addr), [int(x) for x in decomp_n], int(word_size)
+
+    @classmethod
+    def new(cls):  # parameters.rs:167
+        return cls()
+
+    def n(self):
+        return 1 << self.log_n
+
+    def max_addr(self):  # parameters.rs:237
+        return self._max_addr
+
+    def basek(self):
+        return self._base2k
+
+    def rank(self):
+        return self._rank
+
+    def k_glwe_ct(self):
+        return self._k_glwe_ct
+
+    def k_glwe_pt(self):
+        return self._k_glwe_pt
+
+    def k_ggsw_addr(self):
+        return self._k_ggsw_addr
+
+    def k_evk_trace(self):
+        return self._k_evk_trace
+
+    def k_evk_ggsw_inv(self):
+        return self._k_evk_ggsw_inv
+
+    def word_size(self):
+        return self._word_size
+
+    def decomp_n(self):
+        return list(self._decomp_n)
+
+    def dnum_ct(self):  # parameters.rs:273-275
+        return -(-self._k_glwe_ct // self._base2k)
+
+    def dnum_ggsw(self):  # parameters.rs:277-279
+        return -(-self._k_ggsw_addr // self._base2k)
+
+    def base2d(self) -> Base2D:  # parameters.rs:285-287
+        return get_base_2d(self._max_addr, self._decomp_n)
+
+    def rows(self):
+        return -(-self._max_addr // self.n())
+
+    # element counts of the host layouts
+    def glwe_len(self):
+        return self.dnum_ct() * 2 * self.n()
+
+    def ggsw_len(self):
+        return self.dnum_ct() * 2 * self.dnum_ggsw() * 2 * self.n()
+
+    def _c(self) -> _CParams:
+        cp = _CParams()
+        library().fheram_params_default(C.byref(cp))
+        cp.max_addr = self._max_addr
+        cp.word_size = self._word_size
+        cp.n_decomp = len(self._decomp_n)
+        for i, d in enumerate(self._decomp_n):
+            cp.decomp_n[i] = d
+        return cp
+
+
+class EvaluationKeysPrepared:
+    """keys.rs:27-71.  Holds the std-form keys; `prepare` happens on the device when a Ram first
+    uses them (fheram_keys_load)."""
+
+    def __init__(self, gal_els: Sequence[int], atk_glwe, atk_ggsw_inv, tsk_ggsw_inv, atk_ggsw_inv_p: int = -1):
+        self.gal_els = _i64(gal_els)
+        self.atk_glwe = [_i64(k).ravel() for k in atk_glwe]
+        self.atk_ggsw_inv = _i64(atk_ggsw_inv).ravel()
+        self.tsk_ggsw_inv = _i64(tsk_ggsw_inv).ravel()
+        self.atk_ggsw_inv_p = int(atk_ggsw_inv_p)
+
+    @classmethod
+    def from_dict(cls, evk: Dict):
+        return cls(evk["gal_els"], list(evk["atk_glwe"]), evk["atk_ggsw_inv"], evk["tsk"])
+
+
+class Address:
+    """address.rs:21-24: one Coordinate (list of GGSW digits) per Base1D of the plan."""
+
+    def __init__(self, params: Parameters, ggsw_digits):
+        self.base2d = params.base2d()
+        n_digits = self.base2d.as_1d().size()
+        self.digits = [_i64(g).ravel() for g in ggsw_digits]
+        if len(self.digits) != n_digits:
+            raise FheRamError(1, f"address needs {n_digits} GGSW digits, got {len(self.digits)}")
+        self._handles = {}  # ctx handle -> device address
+
+    @classmethod
+    def alloc_from_params(cls, params: Parameters):  # address.rs:58
+        glen = params.ggsw_len()
+        return cls(params, [np.zeros(glen, dtype=np.int64) for _ in range(params.base2d().as_1d().size())])
+
+    def n2(self):  # address.rs:113
+        return len(self.base2d.v)
+
+    def at(self, i):  # address.rs:117
+        s = sum(b.size() for b in self.base2d.v[:i])
+        return self.digits[s:s + self.base2d.v[i].size()]
+
+    def _device(self, ram: "Ram"):
+        h = self._handles.get(id(ram))
+        if h is None:
+            L = library()
+            arr = (I64P * len(self.digits))(*[_p(d) for d in self.digits])
+            out = C.c_void_p()
+            ram._chk(L.fheram_address_create(ram._h, arr, len(self.digits), C.byref(out)))
+            h = _AddrHandle(out.value, ram)
+            self._handles[id(ram)] = h
+        return h.h
+
+
+class _AddrHandle:
+    def __init__(self, h, ram):
+        self.h = h
+        self.ram = ram  # keeps the owning context alive for as long as the device address exists
+
+    def __del__(self):
+        if self.h and _LIB is not None:
+            _LIB.fheram_address_destroy(self.h)
+            self.h = None
+
+
+class Ram:
+    """ram.rs:25-29.  Owns the device-resident sub-RAMs, tree, packer scratch and prepared keys."""
+
+    def __init__(self, params: Optional[Parameters] = None, device: int = 0):
+        self.params = params or Parameters.new()
+        self._h = None
+        L = library()
+        out = C.c_void_p()
+        cp = self.params._c()
+        rc = L.fheram_ctx_create(C.byref(cp), device, C.byref(out))
+        if rc != 0:
+            raise FheRamError(rc, L.fheram_last_error(None).decode())
+        self._h = out.value
+        self._keys = None
+
+    @classmethod
+    def new(cls, device: int = 0):  # ram.rs:59
+        return cls(Parameters.new(), device)
+
+    @classmethod
+    def new_from_ram_params(cls, word_size: int, decomp_n: Sequence[int], max_addr: int, device: int = 0):  # ram.rs:72
+        return cls(Parameters(max_addr=max_addr, decomp_n=decomp_n, word_size=word_size), device)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.fheram_ctx_destroy(self._h)
+            self._h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise FheRamError(rc, library().fheram_last_error(self._h).decode())
+
+    def _use_keys(self, keys: EvaluationKeysPrepared):
+        if self._keys is keys:
+            return
+        L = library()
+        arr = (I64P * len(keys.atk_glwe))(*[_p(k) for k in keys.atk_glwe])
+        self._chk(L.fheram_keys_load(self._h, _p(keys.gal_els), len(keys.gal_els), arr, _p(keys.atk_ggsw_inv),
+                                     keys.atk_ggsw_inv_p, _p(keys.tsk_ggsw_inv)))
+        self._keys = keys
+
+    def _out(self):
+        return np.zeros((self.params.word_size(), self.params.glwe_len()), dtype=np.int64)
+
+    # -- data hand-over (Ram::encrypt_sk output, ram.rs:129-167)
+    def load_encrypted(self, rows: np.ndarray):
+        p = self.params
+        rows = _i64(rows)
+        if rows.size != p.word_size() * p.rows() * p.glwe_len():
+            raise FheRamError(1, f"invalid data: expected {p.word_size()}x{p.rows()} GLWE rows (ram.rs:144-155)")
+        self._chk(library().fheram_ram_upload(self._h, _p(rows)))
+
+    def store_encrypted(self) -> np.ndarray:
+        p = self.params
+        rows = np.zeros((p.word_size(), p.rows(), p.glwe_len()), dtype=np.int64)
+        self._chk(library().fheram_ram_download(self._h, _p(rows)))
+        return rows
+
+    def tree(self, level: int = 0) -> np.ndarray:
+        out = self._out()
+        self._chk(library().fheram_ram_tree_download(self._h, level, _p(out)))
+        return out
+
+    @property
+    def state(self) -> bool:
+        return bool(library().fheram_ram_state(self._h))
+
+    # -- the path
+    def read(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True):  # ram.rs:172
+        self._use_keys(keys)
+        out = self._out() if download else None
+        self._chk(library().fheram_read(self._h, address._device(self), _p(out) if download else None))
+        return out
+
+    def read_prepare_write(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True):  # ram.rs:196
+        self._use_keys(keys)
+        out = self._out() if download else None
+        self._chk(library().fheram_read_prepare_write(self._h, address._device(self), _p(out) if download else None))
+        return out
+
+    def write(self, w, address: Address, keys: EvaluationKeysPrepared):  # ram.rs:226
+        self._use_keys(keys)
+        if w is None:
+            self._chk(library().fheram_write(self._h, None, self.params.word_size(), address._device(self)))
+            return
+        w = _i64(w)
+        n_w = w.shape[0] if w.ndim > 1 else w.size // self.params.glwe_len()
+        self._chk(library().fheram_write(self._h, _p(w), n_w, address._device(self)))
+
+    def stage_words(self, w):
+        w = _i64(w)
+        self._chk(library().fheram_word_stage(self._h, _p(w), w.shape[0]))
+
+    def result(self):
+        out = self._out()
+        self._chk(library().fheram_result_download(self._h, _p(out)))
+        return out
+
+    def sync(self):
+        self._chk(library().fheram_sync(self._h))
+
+    # -- Poulpy-level ops (parity tests / micro-benchmarks)
+    def glwe_external_product(self, a, ggsw):
+        a = _i64(a).reshape(-1, self.params.glwe_len())
+        res = np.zeros_like(a)
+        self._chk(library().fheram_glwe_external_product(self._h, _p(a), a.shape[0], _p(_i64(ggsw).ravel()), _p(res)))
+        return res
+
+    def glwe_automorphism(self, keys, gal_el, mode, a):
+        self._use_keys(keys)
+        a = _i64(a).reshape(-1, self.params.glwe_len())
+        res = np.zeros_like(a)
+        self._chk(library().fheram_glwe_automorphism(self._h, mode, gal_el, _p(a), a.shape[0], _p(res)))
+        return res
+
+    def glwe_trace(self, keys, start, end, a):
+        self._use_keys(keys)
+        a = _i64(a).reshape(-1, self.params.glwe_len())
+        res = np.zeros_like(a)
+        self._chk(library().fheram_glwe_trace(self._h, start, end, _p(a), a.shape[0], _p(res)))
+        return res
+
+    def glwe_pack(self, keys, cts):
+        self._use_keys(keys)
+        cts = _i64(cts).reshape(-1, self.params.glwe_len())
+        out = np.zeros(self.params.glwe_len(), dtype=np.int64)
+        self._chk(library().fheram_glwe_pack(self._h, _p(cts), cts.shape[0], _p(out)))
+        return out
+
+    def ggsw_automorphism_inv(self, keys, ggsw):
+        self._use_keys(keys)
+        g = _i64(ggsw).ravel()
+        out = np.zeros_like(g)
+        self._chk(library().fheram_ggsw_automorphism_inv(self._h, _p(g), _p(out)))
+        return out
+
+    # -- measurement hooks
+    def timer_begin(self):
+        self._chk(library().fheram_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        self._chk(library().fheram_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def profile_enable(self, on=True):
+        self._chk(library().fheram_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._chk(library().fheram_profile_reset(self._h))
+
+    def profile_get(self, cls: str):
+        a, b, ms = C.c_uint64(), C.c_uint64(), C.c_double()
+        self._chk(library().fheram_profile_get(self._h, cls.encode(), C.byref(a), C.byref(b), C.byref(ms)))
+        return {"launches": int(a.value), "blocks": int(b.value), "ms": float(ms.value)}
+
+    def device_info(self):
+        buf = C.create_string_buffer(256)
+        cus = C.c_int()
+        self._chk(library().fheram_device_info(self._h, buf, 256, C.byref(cus)))
+        return {"name": buf.value.decode(), "compute_units": int(cus.value)}

@@ -1,0 +1,760 @@
+// C-ABI library of the MI355X-native FHE-RAM evaluator (include/fheram.h).
+// Host orchestration of Ram::read / read_prepare_write / write (reference: src/ram.rs) over the
+// fused HIP kernels in kernels.hpp.  No CPU compute path exists here: every ciphertext
+// operation is a kernel launch, and a missing GPU is a hard error.
+#include "../../include/fheram.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace fk;
+
+namespace {
+
+typedef unsigned __int128 u128;
+thread_local std::string g_create_err;
+
+uint64_t mulmod_u(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % P_U64); }
+uint64_t powmod_u(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    while (e) { if (e & 1) r = mulmod_u(r, a); a = mulmod_u(a, a); e >>= 1; }
+    return r;
+}
+double centred(uint64_t v) { return v > P_U64 / 2 ? -(double)(P_U64 - v) : (double)v; }
+unsigned brv(unsigned x, int bits) { unsigned r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+
+// Twiddle table in the LDS layout of ntt_dev.hpp: W[2^s + J] (W[i] = psi^bitrev12(i)) is stored
+// at 2^s + j*8^Q + hi with s = 3Q + u, J = hi*2^u + j.
+std::vector<double> make_twiddles() {
+    std::vector<double> tw(N, 0.0);
+    for (int s = 0; s < LOGN; s++) {
+        const int Q = s / 3, u = s % 3, HQ = 1 << (3 * Q);
+        for (int J = 0; J < (1 << s); J++) {
+            const int hi = J >> u, j = J & ((1 << u) - 1);
+            const uint64_t w = powmod_u(PSI_8192, brv((unsigned)((1 << s) + J), LOGN));
+            tw[(1 << s) + j * HQ + hi] = centred(w);
+        }
+    }
+    return tw;
+}
+
+struct ProfCls {
+    uint64_t launches = 0, blocks = 0;
+    double ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace
+
+struct fheram_ctx {
+    fheram_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // derived
+    int ws = 0, n2 = 0, n_digits = 0;
+    size_t rows = 0;
+    std::vector<std::vector<int>> base2d;
+    static constexpr int S_CT = 3, S_ADDR = 4, S_EVK = 4, S_INV = 5, DNUM_CT = 3, DNUM_GGSW = 4;
+    static constexpr size_t GLWE = (size_t)S_CT * 2 * N;                   // elements of a ct
+    static constexpr size_t GLWE4 = (size_t)S_ADDR * 2 * N;                // one GGSW row ct
+    static constexpr size_t GGSW = (size_t)DNUM_CT * 2 * GLWE4;            // elements of a GGSW
+    static constexpr size_t ATK = (size_t)DNUM_CT * S_EVK * 2 * N;         // trace key
+    static constexpr size_t EVK5 = (size_t)DNUM_GGSW * S_INV * 2 * N;      // inverse / tensor key
+    // device
+    double* d_tw = nullptr;
+    double ninv = 0.0;
+    double* d_atk = nullptr;       // [log_n] prepared trace keys
+    double* d_atk_inv = nullptr;
+    double* d_tsk = nullptr;
+    int64_t gal[LOGN];
+    bool keys_loaded = false;
+    int32_t* d_data = nullptr;     // [ws][rows] GLWE
+    int32_t* d_tree = nullptr;     // [ws] GLWE (tree[0][0])
+    int32_t* d_scrA = nullptr;     // [ws][rows]
+    int32_t* d_scrB = nullptr;     // [ws][rows]
+    int32_t* d_res = nullptr;      // [ws]
+    int32_t* d_tmp = nullptr;      // [ws]
+    int32_t* d_w = nullptr;        // [ws]
+    double* d_prep = nullptr;      // [max digits per coordinate] prepared GGSW
+    int32_t* d_ggsw_tmp = nullptr; // [max digits per coordinate] std GGSW (inversion result)
+    int max_digits = 0;
+    bool initialized = false, state = false, words_staged = false;
+    std::vector<int32_t> h_i32;    // host staging
+    // profiling
+    bool profile = false;
+    std::map<std::string, ProfCls> prof;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::string err;
+};
+
+struct fheram_addr {
+    fheram_ctx* ctx;   // owner (identity check only after creation)
+    int32_t* d_ggsw;   // [n_digits] std-form GGSW, int32
+    int n_digits;
+    int device;
+};
+
+namespace {
+
+int fail(fheram_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), FHERAM_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+GlweRef ref(int32_t* p, long sy, long sx) { return GlweRef{p, sy, sx}; }
+
+hipEvent_t get_event(fheram_ctx* c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    fheram_ctx* c; ProfCls* cls = nullptr; hipEvent_t a = nullptr;
+    ProfScope(fheram_ctx* c_, const char* name, uint64_t blocks) : c(c_) {
+        if (!c->profile) return;
+        cls = &c->prof[name];
+        cls->launches++; cls->blocks += blocks;
+        a = get_event(c);
+        hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!cls) return;
+        hipEvent_t b = get_event(c);
+        hipEventRecord(b, c->stream);
+        cls->pending.emplace_back(a, b);
+    }
+};
+void prof_collect(fheram_ctx* c) {
+    for (auto& kv : c->prof) {
+        for (auto& pr : kv.second.pending) {
+            hipEventSynchronize(pr.second);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            kv.second.ms += ms;
+            c->ev_pool.push_back(pr.first); c->ev_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+int ilog2_ceil(size_t x) { int k = 0; while (((size_t)1 << k) < x) k++; return k; }
+int galois_mod(int64_t g) { const int64_t m = 2 * N; return (int)(((g % m) + m) % m); }
+int galois_inv_mod(int g) {   // g odd; g^(N-1) = g^-1 mod 2N
+    int64_t r = 1, b = g, e = N - 1, m = 2 * N;
+    while (e) { if (e & 1) r = r * b % m; b = b * b % m; e >>= 1; }
+    return (int)r;
+}
+int64_t galois_element(int i) {   // GLWE::trace_galois_elements (keys.rs:39,158)
+    if (i == 0) return -1;
+    int64_t g = 5, e = (int64_t)1 << (i - 1), r = 1, m = 2 * N;
+    while (e) { if (e & 1) r = r * g % m; g = g * g % m; e >>= 1; }
+    return r;
+}
+
+// ---- narrowing / widening between the int64 ABI layout and the int32 device layout ---------
+bool narrow(const int64_t* src, int32_t* dst, size_t n) {
+    int64_t bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int64_t v = src[i];
+        bad |= (v > 65536) | (v < -65536);
+        dst[i] = (int32_t)v;
+    }
+    return bad == 0;
+}
+void widen(const int32_t* src, int64_t* dst, size_t n) { for (size_t i = 0; i < n; i++) dst[i] = src[i]; }
+
+int upload_i64(fheram_ctx* c, int32_t* dst, const int64_t* src, size_t n) {
+    c->h_i32.resize(n);
+    if (!narrow(src, c->h_i32.data(), n)) return fail(c, FHERAM_ERR_RANGE, "limb out of the normalised range [-2^16, 2^16]");
+    HIPCHK(c, hipMemcpyAsync(dst, c->h_i32.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FHERAM_OK;
+}
+int download_i64(fheram_ctx* c, int64_t* dst, const int32_t* src, size_t n) {
+    c->h_i32.resize(n);
+    HIPCHK(c, hipMemcpyAsync(c->h_i32.data(), src, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    widen(c->h_i32.data(), dst, n);
+    return FHERAM_OK;
+}
+
+// ---- kernel launchers ---------------------------------------------------------------------
+void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly) {
+    ProfScope ps(c, "prepare", npoly);
+    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->stream, in, out, c->d_tw, c->ninv);
+}
+// res = a (x) ggsw over a (gx, gy) grid
+void launch_ep(fheram_ctx* c, GlweRef a, GlweRef res, const double* ggsw, int gx, int gy) {
+    if (gx <= 0 || gy <= 0) return;
+    ProfScope ps(c, "ext_product", (uint64_t)gx * gy);
+    hipLaunchKernelGGL((k_ext_product<3, 4>), dim3(gx, gy), dim3(T), LDS_BYTES, c->stream, a, res, ggsw, c->d_tw);
+}
+template <int MODE, int SX, int SK, int SO>
+void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
+    if (gx <= 0 || gy <= 0) return;
+    ProfScope ps(c, "keyswitch", (uint64_t)gx * gy);
+    hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO>), dim3(gx, gy), dim3(T), LDS_BYTES, c->stream, ka);
+}
+KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* key, int64_t gal, int t = 0, int rot_mul = 0) {
+    KsArgs ka;
+    ka.a = a; ka.b = b; ka.out = out; ka.key = key; ka.tw = c->d_tw;
+    ka.g = galois_mod(gal); ka.ginv = galois_inv_mod(ka.g); ka.t = t; ka.rot_mul = rot_mul;
+    return ka;
+}
+const double* trace_key(fheram_ctx* c, int i) { return c->d_atk + (size_t)i * fheram_ctx::ATK; }
+
+// CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): chain of d
+// external products; first one reads src, the rest run in place on dst.
+void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, const double* prep, int d, int gx, int gy) {
+    for (int i = 0; i < d; i++) launch_ep(c, i == 0 ? src : dst, dst, prep + (size_t)i * fheram_ctx::GGSW, gx, gy);
+}
+// GLWE::trace(start, end): step i = rsh(1) then a += phi_{g_i}(KS(a)).
+// First step reads `in` (optionally rotated by X^-(x*rot_mul)), the rest run in place on out.
+void trace_steps(fheram_ctx* c, GlweRef in, GlweRef out, int start, int end, int gx, int gy, int rot_mul = 0) {
+    for (int i = start; i < end; i++) {
+        const bool first = (i == start);
+        KsArgs ka = ks_args(c, first ? in : out, first ? in : out, out, trace_key(c, i), c->gal[i], 0, first ? rot_mul : 0);
+        launch_ks<KS_TRACE, 3, 4, 3>(c, ka, gx, gy);
+    }
+}
+// GLWEPacker over `count` leaves per y (ram.rs:425-448), level-synchronous:
+// leaves at src(x = row, y), ping-pong arenas A and B with the same strides as src.
+// Returns the arena that holds the packed result at x = 0.
+int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long sy, long sx, size_t count, int gy) {
+    const int k = ilog2_ceil(count);
+    const int L0 = LOGN - k;
+    int32_t* cur = src;
+    if (L0 > 0) {   // levels where every leaf is alone: a <- rsh(a); a <- a + phi(a)
+        trace_steps(c, ref(src, sy, sx), ref(A, sy, sx), 0, L0, (int)count, gy);
+        cur = A;
+    }
+    size_t live = count;
+    for (int m = 0; m < k; m++) {
+        const int i = L0 + m;
+        const long h = (long)1 << (k - 1 - m);
+        int32_t* nxt = (cur == A) ? B : A;
+        const long n_pair = std::max<long>(0, std::min<long>(h, (long)live - h));
+        const long n_alone = std::min<long>(h, (long)live) - n_pair;
+        if (n_pair > 0) {
+            KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur + h * sx, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i], N >> (i + 1));
+            launch_ks<KS_PAIR, 3, 4, 3>(c, ka, (int)n_pair, gy);
+        }
+        if (n_alone > 0) {
+            KsArgs ka = ks_args(c, ref(cur + n_pair * sx, sy, sx), ref(cur, sy, sx), ref(nxt + n_pair * sx, sy, sx), trace_key(c, i), c->gal[i]);
+            launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)n_alone, gy);
+        }
+        live = std::min<size_t>(live, (size_t)h);
+        cur = nxt;
+    }
+    return cur;
+}
+// CoordinatePrepared::prepare (coordinate_prepared.rs:104-116) for coordinate `ci` of addr.
+int coord_first_digit(const fheram_ctx* c, int ci) { int s = 0; for (int i = 0; i < ci; i++) s += (int)c->base2d[i].size(); return s; }
+void coordinate_prepare(fheram_ctx* c, const fheram_addr* addr, int ci) {
+    const int d = (int)c->base2d[ci].size();
+    launch_prepare(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, c->d_prep, d * (int)(fheram_ctx::GGSW / N));
+}
+// CoordinatePrepared::prepare_inv (coordinate_prepared.rs:121-142): GGSW(X^i) -> GGSW(X^-i).
+void ggsw_inverse(fheram_ctx* c, const int32_t* in, int32_t* tmp, int d) {
+    const long g4 = (long)fheram_ctx::GLWE4;
+    int32_t* inp = const_cast<int32_t*>(in);
+    // GGSW::automorphism, column 0 of every row: res[r][0] = phi_-1(KS(in[r][0]))
+    KsArgs ka = ks_args(c, ref(inp, (long)fheram_ctx::GGSW, 2 * g4), ref(inp, 0, 0), ref(tmp, (long)fheram_ctx::GGSW, 2 * g4), c->d_atk_inv, -1);
+    launch_ks<KS_AUTO, 4, 5, 4>(c, ka, fheram_ctx::DNUM_CT, d);
+    // row expansion with the tensor key: res[r][1] = KS_tsk(res[r][0].mask) + (0, res[r][0].body)
+    KsArgs kt = ks_args(c, ref(tmp, (long)fheram_ctx::GGSW, 2 * g4), ref(tmp, 0, 0), ref(tmp + g4, (long)fheram_ctx::GGSW, 2 * g4), c->d_tsk, 1);
+    launch_ks<KS_TENSOR, 4, 5, 4>(c, kt, fheram_ctx::DNUM_CT, d);
+}
+void coordinate_prepare_inv(fheram_ctx* c, const fheram_addr* addr, int ci) {
+    const int d = (int)c->base2d[ci].size();
+    ggsw_inverse(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, c->d_ggsw_tmp, d);
+    launch_prepare(c, c->d_ggsw_tmp, c->d_prep, d * (int)(fheram_ctx::GGSW / N));
+}
+
+int check_common(fheram_ctx* c, const fheram_addr* addr) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    if (!addr || addr->ctx != c) return fail(c, FHERAM_ERR_INVALID_ARG, "address does not belong to this context (layout mismatch, ram.rs:404)");
+    if (!c->initialized) return fail(c, FHERAM_ERR_UNINITIALIZED, "unitialized memory: self.data.len()=0");
+    if (!c->keys_loaded) return fail(c, FHERAM_ERR_KEYS, "evaluation keys not loaded");
+    return FHERAM_OK;
+}
+
+// Shared body of SubRam::read (ram.rs:382-459) and SubRam::read_prepare_write (ram.rs:461-542)
+// for all sub-RAMs at once.  Result left in d_res.
+int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    const int ws = c->ws;
+    const int R = (int)c->rows;
+    GlweRef data = ref(c->d_data, sy, G);
+    GlweRef res = ref(c->d_res, G, 0);
+    // coordinate 0
+    coordinate_prepare(c, addr, 0);                                                   // ram.rs:416-419 / 496-499
+    const int d0 = (int)c->base2d[0].size();
+    if (c->n2 == 1) {
+        if (prepare_write) {
+            ep_chain(c, ref(c->d_data, sy, 0), ref(c->d_data, sy, 0), c->d_prep, d0, 1, ws);   // ram.rs:502-504 (rows == 1)
+            HIPCHK(c, hipMemcpy2DAsync(c->d_res, G * 4, c->d_data, sy * 4, G * 4, ws, hipMemcpyDeviceToDevice, c->stream));   // ram.rs:537
+        } else {
+            ep_chain(c, ref(c->d_data, sy, 0), ref(c->d_res, G, 0), c->d_prep, d0, 1, ws);     // ram.rs:451
+        }
+    } else {
+        int32_t* leaves;
+        if (prepare_write) {
+            ep_chain(c, data, data, c->d_prep, d0, R, ws);                            // ram.rs:502-504
+            leaves = c->d_data;
+        } else {
+            ep_chain(c, data, ref(c->d_scrA, sy, G), c->d_prep, d0, R, ws);           // ram.rs:429-434
+            leaves = c->d_scrA;
+        }
+        int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws);   // ram.rs:435-448 / 510-521
+        // coordinate 1
+        coordinate_prepare(c, addr, 1);
+        const int d1 = (int)c->base2d[1].size();
+        if (prepare_write) {
+            HIPCHK(c, hipMemcpy2DAsync(c->d_tree, G * 4, packed, sy * 4, G * 4, ws, hipMemcpyDeviceToDevice, c->stream));   // ram.rs:525-527
+            ep_chain(c, ref(c->d_tree, G, 0), ref(c->d_tree, G, 0), c->d_prep, d1, 1, ws);                                  // ram.rs:502-504 (i = 1)
+            HIPCHK(c, hipMemcpyAsync(c->d_res, c->d_tree, (size_t)ws * G * 4, hipMemcpyDeviceToDevice, c->stream));         // ram.rs:535
+        } else {
+            ep_chain(c, ref(packed, sy, 0), res, c->d_prep, d1, 1, ws);               // ram.rs:454
+        }
+    }
+    trace_steps(c, res, res, 0, LOGN, 1, ws);                                         // ram.rs:457 / 540
+    if (prepare_write) c->state = true;                                               // ram.rs:533
+    return FHERAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fheram_params_default(fheram_params* p) {
+    if (!p) return FHERAM_ERR_INVALID_ARG;
+    std::memset(p, 0, sizeof(*p));
+    p->log_n = 12; p->base2k = 17; p->rank = 1;
+    p->k_glwe_pt = 3; p->k_glwe_ct = 51; p->k_ggsw_addr = 68; p->k_evk_trace = 68; p->k_evk_ggsw_inv = 85;
+    p->word_size = 4; p->n_decomp = 4;
+    p->decomp_n[0] = p->decomp_n[1] = p->decomp_n[2] = p->decomp_n[3] = 3;
+    p->max_addr = (uint64_t)1 << 14;
+    return FHERAM_OK;
+}
+
+const char* fheram_last_error(const fheram_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int fheram_ctx_create(const fheram_params* p, int device, fheram_ctx** out) {
+    if (!p || !out) return fail(nullptr, FHERAM_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    // The kernels are built for the reference's cryptographic parameters (parameters.rs:11-18).
+    if (p->log_n != 12 || p->base2k != 17 || p->rank != 1 || p->k_glwe_ct != 51 || p->k_ggsw_addr != 68 ||
+        p->k_evk_trace != 68 || p->k_evk_ggsw_inv != 85)
+        return fail(nullptr, FHERAM_ERR_UNSUPPORTED, "kernels are built for LOG_N=12, BASE2K=17, RANK=1, K_CT=51, K_ADDR=68, K_EVK=68/85");
+    if (p->word_size == 0 || p->word_size > 64 || p->n_decomp == 0 || p->n_decomp > 16 || p->max_addr < 2)
+        return fail(nullptr, FHERAM_ERR_INVALID_ARG, "bad word_size / decomp_n / max_addr");
+    unsigned sum = 0;
+    for (uint32_t i = 0; i < p->n_decomp; i++) { if (p->decomp_n[i] == 0) return fail(nullptr, FHERAM_ERR_INVALID_ARG, "zero digit width"); sum += p->decomp_n[i]; }
+    if (sum != p->log_n) return fail(nullptr, FHERAM_ERR_INVALID_ARG, "DECOMP_N must sum to LOG_N (parameters.rs:168)");
+    if (p->max_addr > ((uint64_t)N * N)) return fail(nullptr, FHERAM_ERR_UNSUPPORTED, "max_addr > N^2 is not supported by the reference either (SURVEY.md 3.1)");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, FHERAM_ERR_DEVICE, "no HIP device: the FHE-RAM evaluator has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, FHERAM_ERR_INVALID_ARG, "bad device index");
+
+    fheram_ctx* c = new fheram_ctx();
+    c->p = *p; c->device = device; c->ws = (int)p->word_size;
+    c->rows = (size_t)((p->max_addr + N - 1) / N);
+    {   // get_base_2d (base.rs:84-108)
+        uint32_t x = (uint32_t)(p->max_addr - 1), bits = 0;
+        while (x) { bits++; x >>= 1; }
+        while (bits != 0) {
+            std::vector<int> v;
+            for (uint32_t i = 0; i < p->n_decomp; i++) {
+                const uint32_t b = p->decomp_n[i];
+                if (b <= bits) { v.push_back((int)b); bits -= b; }
+                else { if (bits != 0) { v.push_back((int)bits); bits = 0; } break; }
+            }
+            c->base2d.push_back(v);
+        }
+    }
+    c->n2 = (int)c->base2d.size();
+    for (auto& v : c->base2d) { c->n_digits += (int)v.size(); c->max_digits = std::max(c->max_digits, (int)v.size()); }
+    for (int i = 0; i < LOGN; i++) c->gal[i] = galois_element(i);
+
+#define CCHK(call)                                                                  \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            g_create_err = std::string(#call) + ": " + hipGetErrorString(e_);       \
+            fheram_ctx_destroy(c);                                                  \
+            return FHERAM_ERR_DEVICE;                                               \
+        }                                                                           \
+    } while (0)
+    CCHK(hipSetDevice(device));
+    CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CCHK(hipEventCreate(&c->t0));
+    CCHK(hipEventCreate(&c->t1));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prepare), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ext_product<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_AUTO, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_TRACE, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_PAIR, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_ADD, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_SUBNEG, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_AUTO, 4, 5, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_TENSOR, 4, 5, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+
+    std::vector<double> tw = make_twiddles();
+    c->ninv = centred(powmod_u((uint64_t)N, P_U64 - 2));
+    CCHK(hipMalloc(&c->d_tw, N * sizeof(double)));
+    CCHK(hipMemcpy(c->d_tw, tw.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    const size_t G = fheram_ctx::GLWE, nrow = (size_t)c->ws * c->rows;
+    CCHK(hipMalloc(&c->d_atk, (size_t)LOGN * fheram_ctx::ATK * sizeof(double)));
+    CCHK(hipMalloc(&c->d_atk_inv, fheram_ctx::EVK5 * sizeof(double)));
+    CCHK(hipMalloc(&c->d_tsk, fheram_ctx::EVK5 * sizeof(double)));
+    CCHK(hipMalloc(&c->d_data, nrow * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_scrA, nrow * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_scrB, nrow * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_tree, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_res, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_tmp, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_w, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_prep, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(double)));
+    CCHK(hipMalloc(&c->d_ggsw_tmp, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(int32_t)));
+    CCHK(hipMemset(c->d_tree, 0, (size_t)c->ws * G * sizeof(int32_t)));
+#undef CCHK
+    *out = c;
+    return FHERAM_OK;
+}
+
+void fheram_ctx_destroy(fheram_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->t0) hipEventDestroy(c->t0);
+    if (c->t1) hipEventDestroy(c->t1);
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+size_t fheram_glwe_len(const fheram_ctx*) { return fheram_ctx::GLWE; }
+size_t fheram_ggsw_len(const fheram_ctx*) { return fheram_ctx::GGSW; }
+size_t fheram_atk_len(const fheram_ctx*) { return fheram_ctx::ATK; }
+size_t fheram_evk_inv_len(const fheram_ctx*) { return fheram_ctx::EVK5; }
+size_t fheram_rows(const fheram_ctx* c) { return c ? c->rows : 0; }
+int fheram_n_digits(const fheram_ctx* c) { return c ? c->n_digits : 0; }
+int fheram_n_coordinates(const fheram_ctx* c) { return c ? c->n2 : 0; }
+
+int fheram_keys_load(fheram_ctx* c, const int64_t* gal_els, int n_gal, const int64_t* const* atk_glwe,
+                     const int64_t* atk_ggsw_inv, int64_t atk_ggsw_inv_p, const int64_t* tsk) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    if (!gal_els || !atk_glwe || !atk_ggsw_inv || !tsk) return fail(c, FHERAM_ERR_INVALID_ARG, "null key pointer");
+    if (n_gal != LOGN) return fail(c, FHERAM_ERR_KEYS, "expected log2(N) trace keys (keys.rs:39)");
+    if (atk_ggsw_inv_p != -1) return fail(c, FHERAM_ERR_KEYS, "auto_key.p() != -1 (coordinate_prepared.rs:134)");
+    HIPCHK(c, hipSetDevice(c->device));
+    // keys may come in any order (the reference keeps them in a HashMap, keys.rs:28): sort by Galois element
+    int order[LOGN];
+    for (int i = 0; i < LOGN; i++) {
+        order[i] = -1;
+        for (int j = 0; j < n_gal; j++) if (gal_els[j] == c->gal[i]) order[i] = j;
+        if (order[i] < 0) return fail(c, FHERAM_ERR_KEYS, "missing trace key for a Galois element of GLWE::trace_galois_elements");
+    }
+    int32_t* d_stage = nullptr;
+    const size_t stage_n = std::max(fheram_ctx::ATK, fheram_ctx::EVK5);
+    HIPCHK(c, hipMalloc(&d_stage, stage_n * sizeof(int32_t)));
+    int rc = FHERAM_OK;
+    for (int i = 0; i < LOGN && rc == FHERAM_OK; i++) {
+        rc = upload_i64(c, d_stage, atk_glwe[order[i]], fheram_ctx::ATK);
+        if (rc == FHERAM_OK) launch_prepare(c, d_stage, c->d_atk + (size_t)i * fheram_ctx::ATK, (int)(fheram_ctx::ATK / N));
+        hipStreamSynchronize(c->stream);
+    }
+    if (rc == FHERAM_OK) rc = upload_i64(c, d_stage, atk_ggsw_inv, fheram_ctx::EVK5);
+    if (rc == FHERAM_OK) { launch_prepare(c, d_stage, c->d_atk_inv, (int)(fheram_ctx::EVK5 / N)); hipStreamSynchronize(c->stream); }
+    if (rc == FHERAM_OK) rc = upload_i64(c, d_stage, tsk, fheram_ctx::EVK5);
+    if (rc == FHERAM_OK) { launch_prepare(c, d_stage, c->d_tsk, (int)(fheram_ctx::EVK5 / N)); hipStreamSynchronize(c->stream); }
+    hipFree(d_stage);
+    if (rc != FHERAM_OK) return rc;
+    HIPCHK(c, hipGetLastError());
+    c->keys_loaded = true;
+    return FHERAM_OK;
+}
+
+int fheram_ram_upload(fheram_ctx* c, const int64_t* rows) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    if (!rows) return fail(c, FHERAM_ERR_INVALID_ARG, "null rows");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = upload_i64(c, c->d_data, rows, (size_t)c->ws * c->rows * fheram_ctx::GLWE);
+    if (rc != FHERAM_OK) return rc;
+    c->initialized = true; c->state = false;
+    return FHERAM_OK;
+}
+int fheram_ram_download(fheram_ctx* c, int64_t* rows) {
+    if (!c || !rows) return FHERAM_ERR_INVALID_ARG;
+    if (!c->initialized) return fail(c, FHERAM_ERR_UNINITIALIZED, "unitialized memory: self.data.len()=0");
+    HIPCHK(c, hipSetDevice(c->device));
+    return download_i64(c, rows, c->d_data, (size_t)c->ws * c->rows * fheram_ctx::GLWE);
+}
+int fheram_ram_tree_download(fheram_ctx* c, int level, int64_t* out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    if (level != 0 || c->n2 < 2) return fail(c, FHERAM_ERR_INVALID_ARG, "tree level does not exist (ram.rs:315-324)");
+    HIPCHK(c, hipSetDevice(c->device));
+    return download_i64(c, out, c->d_tree, (size_t)c->ws * fheram_ctx::GLWE);
+}
+int fheram_ram_state(const fheram_ctx* c) { return c ? (int)c->state : 0; }
+
+int fheram_address_create(fheram_ctx* c, const int64_t* const* ggsw, int n_ggsw, fheram_addr** out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!ggsw) return fail(c, FHERAM_ERR_INVALID_ARG, "null ggsw");
+    if (n_ggsw != c->n_digits) return fail(c, FHERAM_ERR_INVALID_ARG, "address digit count does not match the context's Base2D (ram.rs:404)");
+    HIPCHK(c, hipSetDevice(c->device));
+    fheram_addr* a = new fheram_addr{c, nullptr, n_ggsw, c->device};
+    hipError_t e = hipMalloc(&a->d_ggsw, (size_t)n_ggsw * fheram_ctx::GGSW * sizeof(int32_t));
+    if (e != hipSuccess) { delete a; return fail(c, FHERAM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    for (int i = 0; i < n_ggsw; i++) {
+        if (!ggsw[i]) { fheram_address_destroy(a); return fail(c, FHERAM_ERR_INVALID_ARG, "null ggsw digit"); }
+        int rc = upload_i64(c, a->d_ggsw + (size_t)i * fheram_ctx::GGSW, ggsw[i], fheram_ctx::GGSW);
+        if (rc != FHERAM_OK) { fheram_address_destroy(a); return rc; }
+    }
+    *out = a;
+    return FHERAM_OK;
+}
+void fheram_address_destroy(fheram_addr* a) {
+    if (!a) return;
+    hipSetDevice(a->device);
+    if (a->d_ggsw) hipFree(a->d_ggsw);   // hipFree waits for outstanding work on the buffer
+    delete a;
+}
+
+int fheram_result_download(fheram_ctx* c, int64_t* out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return download_i64(c, out, c->d_res, (size_t)c->ws * fheram_ctx::GLWE);
+}
+int fheram_sync(fheram_ctx* c) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return FHERAM_OK;
+}
+
+int fheram_read(fheram_ctx* c, const fheram_addr* addr, int64_t* out) {
+    int rc = check_common(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    if (c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = read_impl(c, addr, false);
+    if (rc != FHERAM_OK) return rc;
+    HIPCHK(c, hipGetLastError());
+    return out ? fheram_result_download(c, out) : FHERAM_OK;
+}
+int fheram_read_prepare_write(fheram_ctx* c, const fheram_addr* addr, int64_t* out) {
+    int rc = check_common(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    if (c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = read_impl(c, addr, true);
+    if (rc != FHERAM_OK) return rc;
+    HIPCHK(c, hipGetLastError());
+    return out ? fheram_result_download(c, out) : FHERAM_OK;
+}
+int fheram_word_stage(fheram_ctx* c, const int64_t* w, int n_w) {
+    if (!c || !w) return FHERAM_ERR_INVALID_ARG;
+    if (n_w != c->ws) return fail(c, FHERAM_ERR_INVALID_ARG, "w.len() != subrams.len() (ram.rs:243)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = upload_i64(c, c->d_w, w, (size_t)c->ws * fheram_ctx::GLWE);
+    if (rc == FHERAM_OK) c->words_staged = true;
+    return rc;
+}
+// Ram::write, ram.rs:226-294
+int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* addr) {
+    int rc = check_common(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    if (n_w != c->ws) return fail(c, FHERAM_ERR_INVALID_ARG, "w.len() != subrams.len() (ram.rs:243)");
+    if (!c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (w) { rc = fheram_word_stage(c, w, n_w); if (rc != FHERAM_OK) return rc; }
+    else if (!c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    const int ws = c->ws, R = (int)c->rows;
+    GlweRef wref = ref(c->d_w, G, 0);
+    // write_first_step (ram.rs:544-577): t <- normalize(t - trace(t) + w)
+    GlweRef top = (c->n2 != 1) ? ref(c->d_tree, G, 0) : ref(c->d_data, sy, 0);
+    GlweRef tmp = ref(c->d_tmp, G, 0);
+    trace_steps(c, top, tmp, 0, LOGN, 1, ws);
+    {
+        ProfScope ps(c, "elementwise", ws);
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws), dim3(256), 0, c->stream, top, tmp, wref, top);
+    }
+    if (c->n2 == 2) {
+        // mid step for i = 0 (ram.rs:258-276, 579-632)
+        coordinate_prepare_inv(c, addr, 1);
+        ep_chain(c, ref(c->d_tree, G, 0), ref(c->d_tree, G, 0), c->d_prep, (int)c->base2d[1].size(), 1, ws);   // ram.rs:610
+        GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G);
+        trace_steps(c, data, A, 0, LOGN, R, ws);                               // tmp_a = trace(ct_hi)              ram.rs:616
+        trace_steps(c, ref(c->d_tree, G, 0), B, 0, LOGN, R, ws, 1);            // tmp_a = trace(ct_lo * X^-row)     ram.rs:621,629
+        {
+            ProfScope ps(c, "elementwise", (uint64_t)R * ws);
+            hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws), dim3(256), 0, c->stream, data, A, B, data);   // ram.rs:617,625-626
+        }
+        {   // ct_lo has been rotated `rows` times by X^-1 (ram.rs:629)
+            ProfScope ps(c, "elementwise", ws);
+            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws), dim3(256), 0, c->stream, ref(c->d_tree, G, 0), tmp, -R);
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_tree, c->d_tmp, (size_t)ws * G * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    // last step (ram.rs:278-293, 634-649)
+    coordinate_prepare_inv(c, addr, 0);
+    ep_chain(c, ref(c->d_data, sy, G), ref(c->d_data, sy, G), c->d_prep, (int)c->base2d[0].size(), R, ws);
+    c->state = false;
+    HIPCHK(c, hipGetLastError());
+    return FHERAM_OK;
+}
+
+// ---- Poulpy-level operations ---------------------------------------------------------------
+namespace {
+struct DevBuf {
+    int32_t* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+};
+}  // namespace
+
+int fheram_glwe_external_product(fheram_ctx* c, const int64_t* a, int batch, const int64_t* ggsw, int64_t* res) {
+    if (!c || !a || !ggsw || !res || batch <= 0) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t G = fheram_ctx::GLWE;
+    DevBuf da, dg;
+    HIPCHK(c, hipMalloc(&da.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&dg.p, fheram_ctx::GGSW * 4));
+    int rc = upload_i64(c, da.p, a, (size_t)batch * G);
+    if (rc == FHERAM_OK) rc = upload_i64(c, dg.p, ggsw, fheram_ctx::GGSW);
+    if (rc != FHERAM_OK) return rc;
+    launch_prepare(c, dg.p, c->d_prep, (int)(fheram_ctx::GGSW / N));
+    launch_ep(c, ref(da.p, 0, (long)G), ref(da.p, 0, (long)G), c->d_prep, batch, 1);
+    HIPCHK(c, hipGetLastError());
+    return download_i64(c, res, da.p, (size_t)batch * G);
+}
+int fheram_glwe_automorphism(fheram_ctx* c, int mode, int64_t gal_el, const int64_t* a, int batch, int64_t* res) {
+    if (!c || !a || !res || batch <= 0 || mode < 0 || mode > 2) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    if (!c->keys_loaded) return fail(c, FHERAM_ERR_KEYS, "evaluation keys not loaded");
+    int ki = -1;
+    for (int i = 0; i < LOGN; i++) if (c->gal[i] == gal_el) ki = i;
+    if (ki < 0) return fail(c, FHERAM_ERR_KEYS, "no key for this Galois element");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t G = fheram_ctx::GLWE;
+    DevBuf da, dout;
+    HIPCHK(c, hipMalloc(&da.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&dout.p, (size_t)batch * G * 4));
+    int rc = upload_i64(c, da.p, a, (size_t)batch * G);
+    if (rc != FHERAM_OK) return rc;
+    KsArgs ka = ks_args(c, ref(da.p, 0, (long)G), ref(da.p, 0, 0), ref(dout.p, 0, (long)G), trace_key(c, ki), gal_el);
+    if (mode == 0) launch_ks<KS_AUTO, 3, 4, 3>(c, ka, batch, 1);
+    else if (mode == 1) launch_ks<KS_ADD, 3, 4, 3>(c, ka, batch, 1);
+    else launch_ks<KS_SUBNEG, 3, 4, 3>(c, ka, batch, 1);
+    HIPCHK(c, hipGetLastError());
+    return download_i64(c, res, dout.p, (size_t)batch * G);
+}
+int fheram_glwe_trace(fheram_ctx* c, int start, int end, const int64_t* a, int batch, int64_t* res) {
+    if (!c || !a || !res || batch <= 0 || start < 0 || end > LOGN || start > end) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    if (!c->keys_loaded) return fail(c, FHERAM_ERR_KEYS, "evaluation keys not loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t G = fheram_ctx::GLWE;
+    DevBuf da;
+    HIPCHK(c, hipMalloc(&da.p, (size_t)batch * G * 4));
+    int rc = upload_i64(c, da.p, a, (size_t)batch * G);
+    if (rc != FHERAM_OK) return rc;
+    trace_steps(c, ref(da.p, 0, (long)G), ref(da.p, 0, (long)G), start, end, batch, 1);
+    HIPCHK(c, hipGetLastError());
+    return download_i64(c, res, da.p, (size_t)batch * G);
+}
+int fheram_glwe_pack(fheram_ctx* c, const int64_t* cts, int count, int64_t* out) {
+    if (!c || !cts || !out || count <= 0 || count > N) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    if (!c->keys_loaded) return fail(c, FHERAM_ERR_KEYS, "evaluation keys not loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t G = fheram_ctx::GLWE;
+    DevBuf src, A, B;
+    HIPCHK(c, hipMalloc(&src.p, (size_t)count * G * 4));
+    HIPCHK(c, hipMalloc(&A.p, (size_t)count * G * 4));
+    HIPCHK(c, hipMalloc(&B.p, (size_t)count * G * 4));
+    int rc = upload_i64(c, src.p, cts, (size_t)count * G);
+    if (rc != FHERAM_OK) return rc;
+    int32_t* packed = pack_levels(c, src.p, A.p, B.p, 0, (long)G, (size_t)count, 1);
+    HIPCHK(c, hipGetLastError());
+    return download_i64(c, out, packed, G);
+}
+int fheram_ggsw_automorphism_inv(fheram_ctx* c, const int64_t* ggsw_in, int64_t* ggsw_out) {
+    if (!c || !ggsw_in || !ggsw_out) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    if (!c->keys_loaded) return fail(c, FHERAM_ERR_KEYS, "evaluation keys not loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf din;
+    HIPCHK(c, hipMalloc(&din.p, fheram_ctx::GGSW * 4));
+    int rc = upload_i64(c, din.p, ggsw_in, fheram_ctx::GGSW);
+    if (rc != FHERAM_OK) return rc;
+    ggsw_inverse(c, din.p, c->d_ggsw_tmp, 1);
+    HIPCHK(c, hipGetLastError());
+    return download_i64(c, ggsw_out, c->d_ggsw_tmp, fheram_ctx::GGSW);
+}
+
+// ---- measurement hooks ------------------------------------------------------------------------
+int fheram_timer_begin(fheram_ctx* c) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->t0, c->stream));
+    return FHERAM_OK;
+}
+int fheram_timer_end(fheram_ctx* c, float* ms) {
+    if (!c || !ms) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->t1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return FHERAM_OK;
+}
+int fheram_profile_enable(fheram_ctx* c, int on) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    c->profile = on != 0;
+    return FHERAM_OK;
+}
+int fheram_profile_reset(fheram_ctx* c) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    prof_collect(c);
+    c->prof.clear();
+    return FHERAM_OK;
+}
+int fheram_profile_get(fheram_ctx* c, const char* cls, uint64_t* launches, uint64_t* blocks, double* total_ms) {
+    if (!c || !cls) return FHERAM_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    prof_collect(c);
+    auto it = c->prof.find(cls);
+    if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
+    if (blocks) *blocks = it == c->prof.end() ? 0 : it->second.blocks;
+    if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
+    return FHERAM_OK;
+}
+int fheram_device_info(const fheram_ctx* c, char* name, size_t name_len, int* cus) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return FHERAM_ERR_DEVICE;
+    if (name && name_len) { std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (cus) *cus = prop.multiProcessorCount;
+    return FHERAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// Negacyclic NTT over Z_p at N = 4096 for gfx950, p = 2^48 + 57345 (p = 1 mod 8192), carried in
+// FP64: CDNA4 has no 64-bit integer multiplier and v_mul_{lo,hi}_u32 is quarter rate, while
+// v_fma_f64 runs at half the fp32 rate, so residues live in doubles and the modular product is
+// the error-free FMA form  a*b - rint(a*b/p)*p  (5 FP64 ops).  All values are exact integers
+// below 2^53 in magnitude; arithmetic is "lazy" (values drift up to a few p and are pulled back
+// with reduce()).
+//
+// Why this is the same arithmetic as the reference: the reference multiplies limb polynomials
+// with Poulpy's FFT64 backend and rounds to i64 (/root/reference/examples/fhe-ram.rs:3-7,
+// SURVEY.md §0.4); every product on the RAM path is an exact integer negacyclic convolution
+// bounded by 6*2^44 < p/2, so the centred lift of the NTT result is that integer.
+//
+// Decomposition: one workgroup of 512 threads per polynomial, 8 coefficients per thread, four
+// radix-8 register passes (3 butterfly stages each) separated by three LDS exchanges.  Twiddles
+// (4096 doubles, psi^bitrev order, re-laid per stage so that lanes read consecutive or identical
+// addresses) sit in LDS next to the 4096(+pad)-element exchange buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fk {
+
+constexpr int LOGN = 12;
+constexpr int N = 1 << LOGN;
+constexpr int E = 8;             // coefficients per thread
+constexpr int T = N / E;         // threads per workgroup (512 = 8 waves)
+constexpr int LDS_TW = N;        // doubles
+constexpr int LDS_DATA = N + N / 8;  // doubles (exchange buffer incl. padding)
+constexpr size_t LDS_BYTES = (size_t)(LDS_TW + LDS_DATA) * sizeof(double);
+
+constexpr double P = 281474976768001.0;   // 2^48 + 57345, prime
+constexpr double PINV = 1.0 / 281474976768001.0;
+constexpr uint64_t P_U64 = 281474976768001ULL;
+constexpr uint64_t PSI_8192 = 40653067404937ULL;   // primitive 8192-th root of unity mod p
+
+// a*b mod p, |result| < ~(0.5 + |a*b|/p * 2^-51) p.  Exact for |a*b| < 2^101, see DESIGN.md.
+__device__ __forceinline__ double mulmod(double a, double b) {
+    const double h = a * b;
+    const double l = __builtin_fma(a, b, -h);
+    const double q = __builtin_rint(h * PINV);
+    const double r = __builtin_fma(-q, P, h);
+    return r + l;
+}
+// acc + a*b mod p (lazy)
+__device__ __forceinline__ double macmod(double acc, double a, double b) {
+    const double h = a * b;
+    const double l = __builtin_fma(a, b, -h);
+    const double q = __builtin_rint(h * PINV);
+    const double r = __builtin_fma(-q, P, h);
+    return (acc + r) + l;
+}
+// centred representative in [-p/2, p/2]
+__device__ __forceinline__ double reduce(double x) {
+    return __builtin_fma(-__builtin_rint(x * PINV), P, x);
+}
+
+// ---- index patterns --------------------------------------------------------------------
+// Pass Q holds, per thread, the 8 elements  hi*8*S + k*S + lo  with S = 512 >> 3Q,
+// tid = hi*S + lo.  Pass 0 = natural coefficients tid + 512k; pass 3 = 8*tid + k.
+template <int Q>
+__device__ __forceinline__ int pat(int tid, int k) {
+    constexpr int LS = 9 - 3 * Q;  // log2(S)
+    const int hi = tid >> LS;
+    const int lo = tid & ((1 << LS) - 1);
+    return (hi << (LS + 3)) + (k << LS) + lo;
+}
+// LDS layout of exchange X (between pass X and X+1): pad R per 8R block when the read runs
+// (R = 64, 8, 1) are shorter than a 32-lane group, so both sides are bank-conflict free.
+template <int X>
+__device__ __forceinline__ int lay(int idx) {
+    if constexpr (X == 0) return idx;
+    else if constexpr (X == 1) return idx + ((idx >> 6) << 3);
+    else return idx + (idx >> 3);
+}
+
+template <int X>
+__device__ __forceinline__ void exchange_fwd(double (&x)[E], double* data, int tid) {
+    __syncthreads();  // previous readers of the buffer are done
+#pragma unroll
+    for (int k = 0; k < E; k++) data[lay<X>(pat<X>(tid, k))] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = data[lay<X>(pat<X + 1>(tid, k))];
+}
+template <int X>
+__device__ __forceinline__ void exchange_inv(double (&x)[E], double* data, int tid) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E; k++) data[lay<X>(pat<X + 1>(tid, k))] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = data[lay<X>(pat<X>(tid, k))];
+}
+
+// Cooley-Tukey butterfly: (x, y) <- (x + w*y, x - w*y)
+__device__ __forceinline__ void bf(double& x, double& y, double w) {
+    const double t = mulmod(y, w);
+    y = x - t;
+    x = x + t;
+}
+// Gentleman-Sande butterfly with the mirrored forward twiddle: (a, b) <- (a + b, (b - a)*w)
+__device__ __forceinline__ void gs(double& a, double& b, double w) {
+    const double s = a + b;
+    const double d = b - a;
+    a = s;
+    b = mulmod(d, w);
+}
+
+// Twiddle table position of W[2^s + J] (s = 3Q + u, J = hi*2^u + j): 2^s + j*8^Q + hi.
+template <int Q>
+__device__ __forceinline__ void fwd_pass(double (&x)[E], const double* tw, int tid) {
+    constexpr int LS = 9 - 3 * Q;
+    constexpr int HQ = 1 << (3 * Q);
+    const int hi = tid >> LS;
+    {
+        const double w = tw[HQ + hi];
+        bf(x[0], x[4], w); bf(x[1], x[5], w); bf(x[2], x[6], w); bf(x[3], x[7], w);
+    }
+    {
+        const double w0 = tw[2 * HQ + hi], w1 = tw[2 * HQ + HQ + hi];
+        bf(x[0], x[2], w0); bf(x[1], x[3], w0); bf(x[4], x[6], w1); bf(x[5], x[7], w1);
+    }
+    {
+        const double w0 = tw[4 * HQ + hi], w1 = tw[4 * HQ + HQ + hi], w2 = tw[4 * HQ + 2 * HQ + hi], w3 = tw[4 * HQ + 3 * HQ + hi];
+        bf(x[0], x[1], w0); bf(x[2], x[3], w1); bf(x[4], x[5], w2); bf(x[6], x[7], w3);
+    }
+}
+// inverse of fwd_pass<Q> up to the factor 8 (the total 1/N is folded into prepared operands):
+// w^-1 of forward twiddle W[m + J] is -W[2m - 1 - J]; the sign is absorbed by using (b - a).
+template <int Q>
+__device__ __forceinline__ void inv_pass(double (&x)[E], const double* tw, int tid) {
+    constexpr int LS = 9 - 3 * Q;
+    constexpr int HQ = 1 << (3 * Q);
+    const int hm = HQ - 1 - (tid >> LS);
+    {
+        const double w0 = tw[4 * HQ + 3 * HQ + hm], w1 = tw[4 * HQ + 2 * HQ + hm], w2 = tw[4 * HQ + HQ + hm], w3 = tw[4 * HQ + hm];
+        gs(x[0], x[1], w0); gs(x[2], x[3], w1); gs(x[4], x[5], w2); gs(x[6], x[7], w3);
+    }
+    {
+        const double w0 = tw[2 * HQ + HQ + hm], w1 = tw[2 * HQ + hm];
+        gs(x[0], x[2], w0); gs(x[1], x[3], w0); gs(x[4], x[6], w1); gs(x[5], x[7], w1);
+    }
+    {
+        const double w = tw[HQ + hm];
+        gs(x[0], x[4], w); gs(x[1], x[5], w); gs(x[2], x[6], w); gs(x[3], x[7], w);
+    }
+}
+
+// Forward negacyclic NTT.  in: x[k] = coefficient tid + 512k (|x| < 2^20).
+// out: x[k] = transform value at position 8*tid + k (bit-reversed order), |x| < 8p.
+__device__ __forceinline__ void ntt_fwd(double (&x)[E], const double* tw, double* data, int tid) {
+    fwd_pass<0>(x, tw, tid);
+    exchange_fwd<0>(x, data, tid);
+    fwd_pass<1>(x, tw, tid);
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+    exchange_fwd<1>(x, data, tid);
+    fwd_pass<2>(x, tw, tid);
+    exchange_fwd<2>(x, data, tid);
+    fwd_pass<3>(x, tw, tid);
+}
+// Inverse negacyclic NTT without the 1/N factor.  in: x[k] at position 8*tid + k, |x| < 16p.
+// out: x[k] = N * coefficient(tid + 512k) mod p, centred in [-p/2, p/2].
+__device__ __forceinline__ void ntt_inv(double (&x)[E], const double* tw, double* data, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+    inv_pass<3>(x, tw, tid);
+    exchange_inv<2>(x, data, tid);
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+    inv_pass<2>(x, tw, tid);
+    exchange_inv<1>(x, data, tid);
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+    inv_pass<1>(x, tw, tid);
+    exchange_inv<0>(x, data, tid);
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+    inv_pass<0>(x, tw, tid);
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+}
+
+// copy the 4096-entry twiddle table into LDS
+__device__ __forceinline__ void load_twiddles(double* tw_lds, const double* __restrict__ tw_g, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) tw_lds[tid + T * k] = tw_g[tid + T * k];
+    __syncthreads();
+}
+
+// ---- base-2^17 limb arithmetic on exact-integer doubles ------------------
+constexpr int BASE2K = 17;
+constexpr double TWO_B = 131072.0;         // 2^17
+constexpr double INV_TWO_B = 1.0 / 131072.0;
+
+// carry(x) = floor((x + 2^16) / 2^17);  digit(x) = x - carry*2^17 in [-2^16, 2^16)
+__device__ __forceinline__ double carry_of(double x) { return __builtin_floor(__builtin_fma(x, INV_TWO_B, 0.5)); }
+__device__ __forceinline__ double digit_of(double x, double c) { return __builtin_fma(-c, TWO_B, x); }
+
+// vec_znx_big_normalize for one coefficient: in[0..SI) -> out[0..SO), SI >= SO.
+template <int SI, int SO>
+__device__ __forceinline__ void normalize_coeff(const double (&in)[SI], double (&out)[SO]) {
+    double c = 0.0;
+#pragma unroll
+    for (int j = SI - 1; j >= 0; j--) {
+        const double v = in[j] + c;
+        c = carry_of(v);
+        if (j < SO) out[j] = digit_of(v, c);
+    }
+}
+
+// integer digit helpers (int32 is enough: all operands are sums of a few 17-bit digits)
+__device__ __forceinline__ int digit17(int v) { return (int)((unsigned)v << 15) >> 15; }
+
+// vec_znx_rsh_inplace(k = 1) on one coefficient of S limbs (see oracle/znx.hpp rsh_inplace):
+// shift by one limb, then normalise with lsh = 16.
+template <int S>
+__device__ __forceinline__ void rsh1_coeff(const int (&x)[S], int (&y)[S]) {
+    int d = -(x[S - 1] & 1);
+    int c = (x[S - 1] - d) >> 1;
+#pragma unroll
+    for (int j = S - 1; j >= 1; j--) {
+        const int src = x[j - 1];
+        d = -(src & 1);
+        const int cr = (src - d) >> 1;
+        const int dpc = d * 65536 + c;
+        y[j] = digit17(dpc);
+        c = cr + ((dpc - y[j]) >> 17);
+    }
+    y[0] = digit17(c);
+}
+
+}  // namespace fk

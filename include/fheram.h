@@ -1,0 +1,144 @@
+/*
+ * fheram.h — C ABI of the MI355X-native FHE-RAM evaluator.
+ *
+ * Drop-in boundary for the hot path of phantomzone-org/fhe-ram (reference snapshot
+ * 2026-02-13): Ram::read / Ram::read_prepare_write / Ram::write and the types either side of
+ * them.  The reference has no FFI of its own (pure Rust over Poulpy); these entry points are
+ * what a Rust `extern "C"` shim behind the crate's public API (src/lib.rs:12-21) binds — see
+ * INTEGRATION.md for the binding.  Each entry cites the reference interface it replaces.
+ *
+ * Host data interchange = Poulpy's host layouts, little-endian int64:
+ *   GLWE  (size limbs)                : [limb][col 2][N]
+ *   GGSW  (dnum rows, size limbs)     : [row][col_in 2][limb][col_out 2][N]
+ *   GGLWE key (dnum rows, size limbs) : [row][col_in 1][limb][col_out 2][N]
+ * All uploaded limbs must be normalised: -2^(base2k-1) <= x < 2^(base2k-1).
+ *
+ * Threading contract = the reference's: every op takes `&mut self` (ram.rs:172,196,226), so
+ * one op in flight per context; a context is not thread-safe.
+ * Errors: the reference panics (assert!); this ABI returns a status and keeps a message.
+ */
+#ifndef FHERAM_H
+#define FHERAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fheram_ctx fheram_ctx;   /* Ram<B> + Parameters<B> + EvaluationKeysPrepared (ram.rs:25-29) */
+typedef struct fheram_addr fheram_addr; /* Address (address.rs:21-24), device resident              */
+
+enum fheram_status {
+    FHERAM_OK = 0,
+    FHERAM_ERR_INVALID_ARG = 1,   /* size/layout asserts: ram.rs:144-155,243,404,482          */
+    FHERAM_ERR_STATE = 2,         /* state-machine asserts: ram.rs:393-396,472-475,555-558   */
+    FHERAM_ERR_UNINITIALIZED = 3, /* "unitialized memory": ram.rs:182-185,206-209            */
+    FHERAM_ERR_KEYS = 4,          /* missing key / auto_key.p() != -1: coordinate_prepared.rs:134 */
+    FHERAM_ERR_UNSUPPORTED = 5,   /* parameter set the kernels are not built for             */
+    FHERAM_ERR_RANGE = 6,         /* a limb is not normalised                                */
+    FHERAM_ERR_DEVICE = 7         /* HIP runtime error                                       */
+};
+
+/* Parameters (parameters.rs:11-21,147-152). */
+typedef struct fheram_params {
+    uint32_t log_n;          /* LOG_N = 12                     parameters.rs:11 */
+    uint32_t base2k;         /* BASE2K = 17                    parameters.rs:12 */
+    uint32_t rank;           /* RANK = 1                       parameters.rs:13 */
+    uint32_t k_glwe_pt;      /* K_GLWE_PT = 3                  parameters.rs:14 */
+    uint32_t k_glwe_ct;      /* K_GLWE_CT = 3*BASE2K           parameters.rs:15 */
+    uint32_t k_ggsw_addr;    /* K_GGSW_ADDR = 4*BASE2K         parameters.rs:16 */
+    uint32_t k_evk_trace;    /* K_EVK_TRACE = 4*BASE2K         parameters.rs:17 */
+    uint32_t k_evk_ggsw_inv; /* K_EVK_GGSW_INV = 5*BASE2K      parameters.rs:18 */
+    uint32_t word_size;      /* WORDSIZE = 4                   parameters.rs:20 */
+    uint32_t n_decomp;       /* len(DECOMP_N)                  parameters.rs:19 */
+    uint8_t decomp_n[16];    /* DECOMP_N = [3,3,3,3]                            */
+    uint64_t max_addr;       /* MAX_ADDR = 1<<14               parameters.rs:21 */
+} fheram_params;
+
+/* Parameters::new() defaults (parameters.rs:167-176). */
+int fheram_params_default(fheram_params* out);
+
+/* Ram::new / Ram::new_from_ram_params (ram.rs:59-87): allocates every device buffer the
+ * context will ever need (rows, tree, packing scratch, prepared operands) on HIP device
+ * `device`.  Mirrors Ram owning `subrams` + `scratch`. */
+int fheram_ctx_create(const fheram_params* params, int device, fheram_ctx** out);
+void fheram_ctx_destroy(fheram_ctx* ctx);
+/* Message of the last failing call on ctx (ctx == NULL: last fheram_ctx_create failure). */
+const char* fheram_last_error(const fheram_ctx* ctx);
+
+/* Layout sizes in int64 elements (GLWELayout/GGSWLayout/GGLWELayout, parameters.rs:53-104). */
+size_t fheram_glwe_len(const fheram_ctx* ctx);      /* glwe_ct_infos                    */
+size_t fheram_ggsw_len(const fheram_ctx* ctx);      /* ggsw_infos                       */
+size_t fheram_atk_len(const fheram_ctx* ctx);       /* evk_glwe_infos (one key)         */
+size_t fheram_evk_inv_len(const fheram_ctx* ctx);   /* evk_ggsw_infos (one key)         */
+size_t fheram_rows(const fheram_ctx* ctx);          /* GLWE rows per sub-RAM            */
+int fheram_n_digits(const fheram_ctx* ctx);         /* GGSW digits of one Address       */
+int fheram_n_coordinates(const fheram_ctx* ctx);    /* Address::n2 (address.rs:113)     */
+
+/* EvaluationKeysPrepared::alloc + prepare (keys.rs:34-71): std-form keys in, device-prepared
+ * (transform-domain) keys kept in the context.  gal_els must be GLWE::trace_galois_elements
+ * (-1, 5^(2^(i-1)) mod 2N); atk_ggsw_inv_p must be -1 (coordinate_prepared.rs:134). */
+int fheram_keys_load(fheram_ctx* ctx, const int64_t* gal_els, int n_gal, const int64_t* const* atk_glwe,
+                     const int64_t* atk_ggsw_inv, int64_t atk_ggsw_inv_p, const int64_t* tsk_ggsw_inv);
+
+/* Ram::encrypt_sk result hand-over (ram.rs:129-167): rows = [word_size][rows][GLWE]. The
+ * encryption itself is the caller's (host) business.  Resets state to "readable". */
+int fheram_ram_upload(fheram_ctx* ctx, const int64_t* rows);
+int fheram_ram_download(fheram_ctx* ctx, int64_t* rows);
+/* SubRam::tree level `level`, entry 0 of every sub-RAM: [word_size][GLWE] (ram.rs:300). */
+int fheram_ram_tree_download(fheram_ctx* ctx, int level, int64_t* out);
+/* SubRam::state (ram.rs:302): 1 after read_prepare_write, 0 after write. */
+int fheram_ram_state(const fheram_ctx* ctx);
+
+/* Address::alloc_from_params + encrypt_sk result hand-over (address.rs:58,86-109): n_ggsw
+ * std-form GGSW digits, coordinate-major (coordinate 0 digits first). */
+int fheram_address_create(fheram_ctx* ctx, const int64_t* const* ggsw, int n_ggsw, fheram_addr** out);
+void fheram_address_destroy(fheram_addr* addr);
+
+/* Ram::read (ram.rs:172-191).  out: [word_size][GLWE] int64, or NULL to leave the result on
+ * the device (fetch it later with fheram_result_download). */
+int fheram_read(fheram_ctx* ctx, const fheram_addr* addr, int64_t* out);
+/* Ram::read_prepare_write (ram.rs:196-222). */
+int fheram_read_prepare_write(fheram_ctx* ctx, const fheram_addr* addr, int64_t* out);
+/* Ram::write (ram.rs:226-294).  w: n_w GLWEs, each encrypting [w,0,...,0] (ram.rs:228);
+ * w == NULL uses the words staged by fheram_word_stage. */
+int fheram_write(fheram_ctx* ctx, const int64_t* w, int n_w, const fheram_addr* addr);
+int fheram_word_stage(fheram_ctx* ctx, const int64_t* w, int n_w);
+int fheram_result_download(fheram_ctx* ctx, int64_t* out);
+/* Block until every queued operation of ctx has finished. */
+int fheram_sync(fheram_ctx* ctx);
+
+/* ---- Poulpy-level operations reached from the path, exposed for
+ * parity tests and micro-benchmarks.  Inputs/outputs are host buffers in the layouts above. */
+
+/* glwe_external_product (coordinate_prepared.rs:156): res[i] = a[i] (x) ggsw, i < batch. */
+int fheram_glwe_external_product(fheram_ctx* ctx, const int64_t* a, int batch, const int64_t* ggsw, int64_t* res);
+/* glwe_automorphism family with the loaded trace key of Galois element gal_el:
+ * mode 0: res = phi(KS(a));  1: res = a + phi(KS(a));  2: res = a - phi(KS(a)). */
+int fheram_glwe_automorphism(fheram_ctx* ctx, int mode, int64_t gal_el, const int64_t* a, int batch, int64_t* res);
+/* GLWE::trace(start, end) (ram.rs:457,540,572,616,621). */
+int fheram_glwe_trace(fheram_ctx* ctx, int start, int end, const int64_t* a, int batch, int64_t* res);
+/* GLWEPacker (ram.rs:425-448): packs coefficient 0 of cts[0..count) into coefficients
+ * 0..count of one GLWE, feeding them in the RAM's bit-reversed order. */
+int fheram_glwe_pack(fheram_ctx* ctx, const int64_t* cts, int count, int64_t* out);
+/* GGSW::automorphism(p=-1) + tensor-key row expansion (coordinate_prepared.rs:138). */
+int fheram_ggsw_automorphism_inv(fheram_ctx* ctx, const int64_t* ggsw_in, int64_t* ggsw_out);
+
+/* ---- Measurement hooks (bench.py).  HIP events recorded on the context's own stream. */
+int fheram_timer_begin(fheram_ctx* ctx);
+int fheram_timer_end(fheram_ctx* ctx, float* elapsed_ms);
+/* Per-kernel-class timing: when enabled, every launch of the hot kernels is bracketed by HIP
+ * events on the launch stream; totals are read back per class name
+ * ("ext_product", "keyswitch", "prepare", "elementwise"). */
+int fheram_profile_enable(fheram_ctx* ctx, int on);
+int fheram_profile_get(fheram_ctx* ctx, const char* kernel_class, uint64_t* launches, uint64_t* blocks, double* total_ms);
+int fheram_profile_reset(fheram_ctx* ctx);
+/* Device properties of the context's GPU (name, CU count) for the bench report. */
+int fheram_device_info(const fheram_ctx* ctx, char* name, size_t name_len, int* compute_units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHERAM_H */

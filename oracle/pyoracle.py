@@ -1,0 +1,459 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/README.md).
+
+ctypes binding of oracle/liboracle.so (the CPU restatement of the fhe-ram hot path).
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (fhe-ram_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+I64P = C.POINTER(C.c_int64)
+U8P = C.POINTER(C.c_uint8)
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with the committed Makefile (g++)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.fo_last_error.restype = C.c_char_p
+        L.fo_ctx_new.restype = C.c_void_p
+        L.fo_ctx_new.argtypes = [C.c_int] * 7 + [U8P, C.c_int, C.c_int, C.c_uint64]
+        L.fo_ctx_free.argtypes = [C.c_void_p]
+        L.fo_ctx_max_big.restype = C.c_int64
+        L.fo_ctx_max_big.argtypes = [C.c_void_p]
+        L.fo_ctx_reset_stats.argtypes = [C.c_void_p]
+        L.fo_ctx_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.fo_base1d_max.restype = C.c_uint64
+        L.fo_base1d_max.argtypes = [U8P, C.c_int]
+        L.fo_base1d_gap.restype = C.c_uint64
+        L.fo_base1d_gap.argtypes = [U8P, C.c_int, C.c_uint64]
+        L.fo_base1d_decomp.argtypes = [U8P, C.c_int, C.c_uint32, U8P]
+        L.fo_base1d_recomp.restype = C.c_uint32
+        L.fo_base1d_recomp.argtypes = [U8P, C.c_int, U8P]
+        L.fo_get_base_2d.restype = C.c_int
+        L.fo_get_base_2d.argtypes = [C.c_uint32, U8P, C.c_int, U8P, C.POINTER(C.c_int), C.c_int]
+        L.fo_reverse_bits_msb.restype = C.c_uint64
+        L.fo_reverse_bits_msb.argtypes = [C.c_uint64, C.c_uint32]
+        L.fo_galois_element.restype = C.c_int64
+        L.fo_galois_element.argtypes = [C.c_int, C.c_int]
+        L.fo_cast_u8_to_signed.restype = C.c_int64
+        L.fo_cast_u8_to_signed.argtypes = [C.c_uint8, C.c_int]
+        L.fo_big_normalize.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, I64P, I64P]
+        L.fo_glwe_rsh.argtypes = [C.c_void_p, C.c_int, I64P, C.c_int]
+        L.fo_glwe_normalize.argtypes = [C.c_void_p, I64P, C.c_int]
+        L.fo_glwe_rotate.argtypes = [C.c_void_p, C.c_int64, I64P, I64P, C.c_int]
+        L.fo_poly_automorphism.argtypes = [C.c_int, C.c_int64, I64P, I64P]
+        L.fo_negacyclic_ntt.argtypes = [C.c_void_p, I64P, I64P, I64P]
+        L.fo_negacyclic_schoolbook.argtypes = [C.c_int, I64P, I64P, I64P]
+        L.fo_secret_gen.argtypes = [C.c_void_p, C.c_uint64, I64P]
+        L.fo_evk_gen.argtypes = [C.c_void_p, I64P, C.c_uint64, C.c_uint64, I64P, I64P, I64P, I64P]
+        L.fo_ram_encrypt.argtypes = [C.c_void_p, U8P, C.c_uint64, I64P, C.c_uint64, C.c_uint64, I64P]
+        L.fo_address_n_digits.argtypes = [C.c_void_p]
+        L.fo_address_encrypt.argtypes = [C.c_void_p, C.c_uint32, I64P, C.c_uint64, C.c_uint64, I64P]
+        L.fo_glwe_encrypt_coeff0.argtypes = [C.c_void_p, C.c_uint8, I64P, C.c_uint64, C.c_uint64, I64P]
+        L.fo_glwe_decrypt.argtypes = [C.c_void_p, I64P, C.c_int64, I64P, C.c_int, I64P, C.POINTER(C.c_double)]
+        L.fo_ggsw_encrypt.argtypes = [C.c_void_p, I64P, I64P, C.c_uint64, C.c_uint64, I64P]
+        L.fo_keys_prepare.restype = C.c_void_p
+        L.fo_keys_prepare.argtypes = [C.c_void_p, I64P, C.c_int, I64P, I64P, I64P]
+        L.fo_keys_free.argtypes = [C.c_void_p]
+        L.fo_address_new.restype = C.c_void_p
+        L.fo_address_new.argtypes = [C.c_void_p, I64P]
+        L.fo_address_free.argtypes = [C.c_void_p]
+        L.fo_glwe_external_product.argtypes = [C.c_void_p, I64P, I64P, I64P]
+        L.fo_glwe_automorphism.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, I64P, I64P]
+        L.fo_glwe_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, I64P]
+        L.fo_glwe_pack.argtypes = [C.c_void_p, C.c_void_p, I64P, U8P, I64P]
+        L.fo_ggsw_automorphism_inv.argtypes = [C.c_void_p, C.c_void_p, I64P, I64P]
+        L.fo_ram_new.restype = C.c_void_p
+        L.fo_ram_new.argtypes = [C.c_void_p]
+        L.fo_ram_free.argtypes = [C.c_void_p]
+        L.fo_ram_load.argtypes = [C.c_void_p, I64P]
+        L.fo_ram_store.argtypes = [C.c_void_p, I64P]
+        L.fo_ram_tree.argtypes = [C.c_void_p, C.c_int, I64P]
+        L.fo_ram_state.argtypes = [C.c_void_p]
+        L.fo_ram_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, I64P]
+        L.fo_ram_read_prepare_write.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, I64P]
+        L.fo_ram_write.argtypes = [C.c_void_p, I64P, C.c_int, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.int64 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(I64P)
+
+
+def _u8(a: np.ndarray):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(U8P)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise OracleError(lib().fo_last_error().decode())
+
+
+@dataclass
+class OParams:
+    """parameters.rs:11-21 (defaults) + run-time RAM parameters (ram.rs:72-87)."""
+    log_n: int = 12
+    base2k: int = 17
+    k_glwe_pt: int = 3
+    k_glwe_ct: int = 51
+    k_ggsw_addr: int = 68
+    k_evk_trace: int = 68
+    k_evk_ggsw_inv: int = 85
+    decomp_n: List[int] = field(default_factory=lambda: [3, 3, 3, 3])
+    word_size: int = 4
+    max_addr: int = 1 << 14
+
+    @property
+    def n(self):
+        return 1 << self.log_n
+
+    def _sz(self, k):
+        return -(-k // self.base2k)
+
+    @property
+    def size_ct(self):
+        return self._sz(self.k_glwe_ct)
+
+    @property
+    def size_addr(self):
+        return self._sz(self.k_ggsw_addr)
+
+    @property
+    def size_evk_trace(self):
+        return self._sz(self.k_evk_trace)
+
+    @property
+    def size_evk_inv(self):
+        return self._sz(self.k_evk_ggsw_inv)
+
+    @property
+    def dnum_ct(self):
+        return self._sz(self.k_glwe_ct)
+
+    @property
+    def dnum_ggsw(self):
+        return self._sz(self.k_ggsw_addr)
+
+    @property
+    def rows(self):
+        return -(-self.max_addr // self.n)
+
+    @property
+    def glwe_len(self):
+        return self.size_ct * 2 * self.n
+
+    @property
+    def ggsw_len(self):
+        return self.dnum_ct * 2 * self.size_addr * 2 * self.n
+
+    @property
+    def atk_trace_len(self):
+        return self.dnum_ct * self.size_evk_trace * 2 * self.n
+
+    @property
+    def evk_inv_len(self):
+        return self.dnum_ggsw * self.size_evk_inv * 2 * self.n
+
+
+def get_base_2d(value: int, base: List[int]) -> List[List[int]]:
+    b = np.array(base, dtype=np.uint8)
+    out = np.zeros(64, dtype=np.uint8)
+    lens = (C.c_int * 16)()
+    q = lib().fo_get_base_2d(value, _u8(b), len(base), _u8(out), lens, 16)
+    assert q >= 0
+    res, k = [], 0
+    for i in range(q):
+        res.append([int(x) for x in out[k:k + lens[i]]])
+        k += lens[i]
+    return res
+
+
+class Base1D:
+    def __init__(self, d):
+        self.d = [int(x) for x in d]
+        self._a = np.array(self.d, dtype=np.uint8) if self.d else np.zeros(1, dtype=np.uint8)
+
+    def max(self):
+        return int(lib().fo_base1d_max(_u8(self._a), len(self.d)))
+
+    def gap(self, log_n):
+        return int(lib().fo_base1d_gap(_u8(self._a), len(self.d), log_n))
+
+    def decomp(self, value):
+        out = np.zeros(max(1, len(self.d)), dtype=np.uint8)
+        lib().fo_base1d_decomp(_u8(self._a), len(self.d), value, _u8(out))
+        return [int(x) for x in out[:len(self.d)]]
+
+    def recomp(self, dec):
+        a = np.array(list(dec) + [0], dtype=np.uint8)
+        return int(lib().fo_base1d_recomp(_u8(self._a), len(self.d), _u8(a)))
+
+
+class Base2D:
+    def __init__(self, v):
+        self.v = [Base1D(x) for x in v]
+
+    def as_1d(self):
+        return Base1D([x for b in self.v for x in b.d])
+
+    def max(self):
+        return self.as_1d().max()
+
+    def max_len(self):
+        return max([len(b.d) for b in self.v], default=0)
+
+    def decomp(self, value):
+        return self.as_1d().decomp(value)
+
+    def recomp(self, dec):
+        return self.as_1d().recomp(dec)
+
+
+class Oracle:
+    """One oracle context (parameters + transform tables)."""
+
+    def __init__(self, params: Optional[OParams] = None):
+        self.p = params or OParams()
+        d = np.array(self.p.decomp_n, dtype=np.uint8)
+        self.h = lib().fo_ctx_new(self.p.log_n, self.p.base2k, self.p.k_glwe_pt, self.p.k_glwe_ct, self.p.k_ggsw_addr,
+                                  self.p.k_evk_trace, self.p.k_evk_ggsw_inv, _u8(d), len(d), self.p.word_size,
+                                  self.p.max_addr)
+        if not self.h:
+            raise OracleError(lib().fo_last_error().decode())
+        self.n_digits = lib().fo_address_n_digits(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().fo_ctx_free(self.h)
+            self.h = None
+
+    # -- stats
+    def max_big(self):
+        return int(lib().fo_ctx_max_big(self.h))
+
+    def counters(self):
+        o = (C.c_uint64 * 3)()
+        lib().fo_ctx_counters(self.h, o)
+        return {"ep": int(o[0]), "ks": int(o[1]), "prepare": int(o[2])}
+
+    def reset_stats(self):
+        lib().fo_ctx_reset_stats(self.h)
+
+    # -- setup (examples/fhe-ram.rs:34-95)
+    def secret_gen(self, seed):
+        sk = np.zeros(self.p.n, dtype=np.int64)
+        lib().fo_secret_gen(self.h, seed, _p(sk))
+        return sk
+
+    def evk_gen(self, sk, seed_a, seed_e):
+        p = self.p
+        gal = np.zeros(p.log_n, dtype=np.int64)
+        atk = np.zeros((p.log_n, p.atk_trace_len), dtype=np.int64)
+        inv = np.zeros(p.evk_inv_len, dtype=np.int64)
+        tsk = np.zeros(p.evk_inv_len, dtype=np.int64)
+        _chk(lib().fo_evk_gen(self.h, _p(sk), seed_a, seed_e, _p(gal), _p(atk), _p(inv), _p(tsk)))
+        return {"gal_els": gal, "atk_glwe": atk, "atk_ggsw_inv": inv, "tsk": tsk}
+
+    def ram_encrypt(self, data: np.ndarray, sk, seed_a, seed_e):
+        p = self.p
+        rows = np.zeros((p.word_size, p.rows, p.glwe_len), dtype=np.int64)
+        _chk(lib().fo_ram_encrypt(self.h, _u8(data), data.size, _p(sk), seed_a, seed_e, _p(rows)))
+        return rows
+
+    def address_encrypt(self, value, sk, seed_a, seed_e):
+        out = np.zeros((self.n_digits, self.p.ggsw_len), dtype=np.int64)
+        _chk(lib().fo_address_encrypt(self.h, value, _p(sk), seed_a, seed_e, _p(out)))
+        return out
+
+    def glwe_encrypt_coeff0(self, value, sk, seed_a, seed_e):
+        ct = np.zeros(self.p.glwe_len, dtype=np.int64)
+        _chk(lib().fo_glwe_encrypt_coeff0(self.h, value, _p(sk), seed_a, seed_e, _p(ct)))
+        return ct
+
+    def glwe_decrypt(self, ct, want, sk, coeff=0):
+        v = C.c_int64()
+        nz = C.c_double()
+        ct = np.ascontiguousarray(ct, dtype=np.int64)
+        _chk(lib().fo_glwe_decrypt(self.h, _p(ct), want, _p(sk), coeff, C.byref(v), C.byref(nz)))
+        return int(v.value), float(nz.value)
+
+    def ggsw_encrypt(self, scalar, sk, seed_a, seed_e):
+        out = np.zeros(self.p.ggsw_len, dtype=np.int64)
+        _chk(lib().fo_ggsw_encrypt(self.h, _p(scalar), _p(sk), seed_a, seed_e, _p(out)))
+        return out
+
+    @staticmethod
+    def cast_u8_to_signed(v, bits):
+        return int(lib().fo_cast_u8_to_signed(v, bits))
+
+    # -- handles
+    def keys_prepare(self, evk):
+        atk = np.ascontiguousarray(evk["atk_glwe"])
+        h = lib().fo_keys_prepare(self.h, _p(evk["gal_els"]), len(evk["gal_els"]), _p(atk), _p(evk["atk_ggsw_inv"]), _p(evk["tsk"]))
+        if not h:
+            raise OracleError(lib().fo_last_error().decode())
+        return _Handle(h, lib().fo_keys_free)
+
+    def address_new(self, ggsw_all):
+        a = np.ascontiguousarray(ggsw_all)
+        h = lib().fo_address_new(self.h, _p(a))
+        if not h:
+            raise OracleError(lib().fo_last_error().decode())
+        return _Handle(h, lib().fo_address_free)
+
+    # -- Poulpy-level ops
+    def big_normalize(self, a: np.ndarray, res_size: int):
+        a = np.ascontiguousarray(a)
+        a_size, n = a.shape
+        res = np.zeros((res_size, n), dtype=np.int64)
+        lib().fo_big_normalize(self.p.base2k, n, res_size, a_size, _p(a), _p(res))
+        return res
+
+    def glwe_rsh(self, k, glwe):
+        g = np.array(glwe, dtype=np.int64).ravel().copy()
+        lib().fo_glwe_rsh(self.h, k, _p(g), g.size // (2 * self.p.n))
+        return g
+
+    def glwe_normalize(self, glwe):
+        g = np.array(glwe, dtype=np.int64).ravel().copy()
+        lib().fo_glwe_normalize(self.h, _p(g), g.size // (2 * self.p.n))
+        return g
+
+    def glwe_rotate(self, k, glwe):
+        g = np.ascontiguousarray(glwe, dtype=np.int64).ravel()
+        out = np.zeros_like(g)
+        lib().fo_glwe_rotate(self.h, k, _p(g), _p(out), g.size // (2 * self.p.n))
+        return out
+
+    def poly_automorphism(self, g, poly):
+        a = np.ascontiguousarray(poly, dtype=np.int64)
+        out = np.zeros_like(a)
+        lib().fo_poly_automorphism(a.size, g, _p(a), _p(out))
+        return out
+
+    def negacyclic_ntt(self, a, b):
+        out = np.zeros(self.p.n, dtype=np.int64)
+        lib().fo_negacyclic_ntt(self.h, _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), _p(out))
+        return out
+
+    @staticmethod
+    def negacyclic_schoolbook(a, b):
+        out = np.zeros(a.size, dtype=np.int64)
+        lib().fo_negacyclic_schoolbook(a.size, _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), _p(out))
+        return out
+
+    def glwe_external_product(self, a, ggsw):
+        res = np.zeros(self.p.glwe_len, dtype=np.int64)
+        _chk(lib().fo_glwe_external_product(self.h, _p(np.ascontiguousarray(a).ravel()), _p(np.ascontiguousarray(ggsw).ravel()), _p(res)))
+        return res
+
+    def glwe_automorphism(self, keys, gal_el, mode, a):
+        res = np.zeros(self.p.glwe_len, dtype=np.int64)
+        _chk(lib().fo_glwe_automorphism(self.h, keys.h, gal_el, mode, _p(np.ascontiguousarray(a).ravel()), _p(res)))
+        return res
+
+    def glwe_trace(self, keys, start, end, a):
+        g = np.array(a, dtype=np.int64).ravel().copy()
+        _chk(lib().fo_glwe_trace(self.h, keys.h, start, end, _p(g)))
+        return g
+
+    def glwe_pack(self, keys, cts, present):
+        cts = np.ascontiguousarray(cts, dtype=np.int64)
+        present = np.ascontiguousarray(present, dtype=np.uint8)
+        assert present.size == self.p.n
+        out = np.zeros(self.p.glwe_len, dtype=np.int64)
+        _chk(lib().fo_glwe_pack(self.h, keys.h, _p(cts), _u8(present), _p(out)))
+        return out
+
+    def ggsw_automorphism_inv(self, keys, ggsw):
+        out = np.zeros(self.p.ggsw_len, dtype=np.int64)
+        _chk(lib().fo_ggsw_automorphism_inv(self.h, keys.h, _p(np.ascontiguousarray(ggsw).ravel()), _p(out)))
+        return out
+
+    def ram_new(self):
+        return ORam(self)
+
+
+class _Handle:
+    def __init__(self, h, free):
+        self.h, self._free = h, free
+
+    def __del__(self):
+        if self.h:
+            self._free(self.h)
+            self.h = None
+
+
+class ORam:
+    """ram.rs Ram (oracle)."""
+
+    def __init__(self, o: Oracle):
+        self.o = o
+        self.h = lib().fo_ram_new(o.h)
+        if not self.h:
+            raise OracleError(lib().fo_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().fo_ram_free(self.h)
+            self.h = None
+
+    def load(self, rows):
+        lib().fo_ram_load(self.h, _p(np.ascontiguousarray(rows)))
+
+    def store(self):
+        p = self.o.p
+        rows = np.zeros((p.word_size, p.rows, p.glwe_len), dtype=np.int64)
+        lib().fo_ram_store(self.h, _p(rows))
+        return rows
+
+    def tree(self, lvl=0):
+        out = np.zeros((self.o.p.word_size, self.o.p.glwe_len), dtype=np.int64)
+        if lib().fo_ram_tree(self.h, lvl, _p(out)) != 0:
+            return None
+        return out
+
+    @property
+    def state(self):
+        return bool(lib().fo_ram_state(self.h))
+
+    def read(self, addr, keys):
+        out = np.zeros((self.o.p.word_size, self.o.p.glwe_len), dtype=np.int64)
+        _chk(lib().fo_ram_read(self.h, addr.h, keys.h, _p(out)))
+        return out
+
+    def read_prepare_write(self, addr, keys):
+        out = np.zeros((self.o.p.word_size, self.o.p.glwe_len), dtype=np.int64)
+        _chk(lib().fo_ram_read_prepare_write(self.h, addr.h, keys.h, _p(out)))
+        return out
+
+    def write(self, w, addr, keys):
+        w = np.ascontiguousarray(w, dtype=np.int64)
+        _chk(lib().fo_ram_write(self.h, _p(w), w.shape[0], addr.h, keys.h))
