@@ -35,15 +35,26 @@ struct Ntt {
         while (e) { if (e & 1) r = mulmod(r, a); a = mulmod(a, a); e >>= 1; }
         return r;
     }
-    static uint64_t shoup(uint64_t w_) { return (uint64_t)(((u128)w_ << 64) / Q); }
+    // floor(w * 2^64 / Q): estimate in 80-bit floating point, then correct exactly (a 128/64-bit
+    // division per coefficient would dominate the cost of preparing an operand).
+    static uint64_t shoup(uint64_t w_) {
+        static const long double inv = 18446744073709551616.0L / (long double)Q;
+        uint64_t q = (uint64_t)((long double)w_ * inv);
+        u128 num = (u128)w_ << 64;
+        u128 prod = (u128)q * Q;
+        while (prod > num) { q--; prod -= Q; }
+        while (num - prod >= Q) { q++; prod += Q; }
+        return q;
+    }
     // x*w mod Q with precomputed ws = floor(w*2^64/Q); x < 2^64 arbitrary, result in [0,Q)
     static inline uint64_t mul_shoup(uint64_t x, uint64_t w_, uint64_t ws_) {
         uint64_t q = (uint64_t)(((u128)x * ws_) >> 64);
         uint64_t r = x * w_ - q * Q;
-        return r >= Q ? r - Q : r;
+        return r - (Q & (0 - (uint64_t)(r >= Q)));
     }
-    static inline uint64_t addmod(uint64_t a, uint64_t b) { uint64_t s = a + b; return s >= Q ? s - Q : s; }
-    static inline uint64_t submod(uint64_t a, uint64_t b) { return a >= b ? a - b : a + Q - b; }
+    // branch-free: the comparisons are data dependent and would mispredict half of the time
+    static inline uint64_t addmod(uint64_t a, uint64_t b) { uint64_t s = a + b; return s - (Q & (0 - (uint64_t)(s >= Q))); }
+    static inline uint64_t submod(uint64_t a, uint64_t b) { uint64_t d = a - b; return d + (Q & (0 - (uint64_t)(a < b))); }
     static inline uint64_t to_mod(int64_t x) { return x < 0 ? (uint64_t)(x + (int64_t)Q) : (uint64_t)x; }
     static inline int64_t center(uint64_t u) { return u > Q / 2 ? (int64_t)(u - Q) : (int64_t)u; }
 
