@@ -43,7 +43,8 @@ class _CParams(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libfheram.so")
+    # FHERAM_LIB selects an alternative build of the same HIP library (kernel-tuning experiments)
+    return os.environ.get("FHERAM_LIB") or os.path.join(_HERE, "libfheram.so")
 
 
 # every symbol include/fheram.h declares: (name, restype, argtypes)

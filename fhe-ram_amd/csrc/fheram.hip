@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -29,11 +30,11 @@ double centred(uint64_t v) { return v > P_U64 / 2 ? -(double)(P_U64 - v) : (doub
 unsigned brv(unsigned x, int bits) { unsigned r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 
 // Twiddle table in the LDS layout of ntt_dev.hpp: W[2^s + J] (W[i] = psi^bitrev12(i)) is stored
-// at 2^s + j*8^Q + hi with s = 3Q + u, J = hi*2^u + j.
+// at 2^s + j*E^Q + hi with s = LOGE*Q + u, J = hi*2^u + j.
 std::vector<double> make_twiddles() {
     std::vector<double> tw(N, 0.0);
     for (int s = 0; s < LOGN; s++) {
-        const int Q = s / 3, u = s % 3, HQ = 1 << (3 * Q);
+        const int Q = s / LOGE, u = s % LOGE, HQ = 1 << (LOGE * Q);
         for (int J = 0; J < (1 << s); J++) {
             const int hi = J >> u, j = J & ((1 << u) - 1);
             const uint64_t w = powmod_u(PSI_8192, brv((unsigned)((1 << s) + J), LOGN));
@@ -75,11 +76,16 @@ struct fheram_ctx {
     bool keys_loaded = false;
     int32_t* d_data = nullptr;     // [ws][rows] GLWE
     int32_t* d_tree = nullptr;     // [ws] GLWE (tree[0][0])
-    int32_t* d_scrA = nullptr;     // [ws][rows]
+    int32_t* d_scrA = nullptr;     // [ws][rows]  ping-pong arenas: every fused kernel is out of place
     int32_t* d_scrB = nullptr;     // [ws][rows]
+    int32_t* d_scrC = nullptr;     // [ws][rows]
     int32_t* d_res = nullptr;      // [ws]
     int32_t* d_tmp = nullptr;      // [ws]
+    int32_t* d_tmp2 = nullptr;     // [ws]
     int32_t* d_w = nullptr;        // [ws]
+    int nco = 0;                   // output columns per workgroup: 1 = split by column (2 workgroups per
+                                   // ciphertext), 2 = one workgroup, 0 = choose per launch from the batch size
+    int cus = 256;
     double* d_prep = nullptr;      // [max digits per coordinate] prepared GGSW
     int32_t* d_ggsw_tmp = nullptr; // [max digits per coordinate] std GGSW (inversion result)
     int max_digits = 0;
@@ -190,21 +196,34 @@ int download_i64(fheram_ctx* c, int64_t* dst, const int32_t* src, size_t n) {
 }
 
 // ---- kernel launchers ---------------------------------------------------------------------
+// One workgroup per ciphertext does the least work (no repeated forward transforms); splitting by
+// output column doubles the number of workgroups, which pays while the batch cannot fill the CUs.
+int pick_nco(const fheram_ctx* c, int gx, int gy) {
+    if (c->nco != 0) return c->nco;
+    return ((long)gx * gy * 2 <= c->cus) ? 1 : 2;
+}
 void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly) {
     ProfScope ps(c, "prepare", npoly);
     hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->stream, in, out, c->d_tw, c->ninv);
 }
-// res = a (x) ggsw over a (gx, gy) grid
+// res = a (x) ggsw over a (gx, gy) grid of ciphertexts; res must not alias a
 void launch_ep(fheram_ctx* c, GlweRef a, GlweRef res, const double* ggsw, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "ext_product", (uint64_t)gx * gy);
-    hipLaunchKernelGGL((k_ext_product<3, 4>), dim3(gx, gy), dim3(T), LDS_BYTES, c->stream, a, res, ggsw, c->d_tw);
+    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_ext_product<3, 4, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->stream, a, res, ggsw, c->d_tw);
+    else hipLaunchKernelGGL((k_ext_product<3, 4, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->stream, a, res, ggsw, c->d_tw);
 }
 template <int MODE, int SX, int SK, int SO>
 void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "keyswitch", (uint64_t)gx * gy);
-    hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO>), dim3(gx, gy), dim3(T), LDS_BYTES, c->stream, ka);
+    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->stream, ka);
+    else hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->stream, ka);
+}
+void launch_copy(fheram_ctx* c, GlweRef src, GlweRef dst, int gx, int gy) {
+    if (gx <= 0 || gy <= 0) return;
+    ProfScope ps(c, "elementwise", (uint64_t)gx * gy);
+    hipLaunchKernelGGL((k_copy<3>), dim3(gx, gy), dim3(256), 0, c->stream, src, dst);
 }
 KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* key, int64_t gal, int t = 0, int rot_mul = 0) {
     KsArgs ka;
@@ -213,37 +232,56 @@ KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* k
     return ka;
 }
 const double* trace_key(fheram_ctx* c, int i) { return c->d_atk + (size_t)i * fheram_ctx::ATK; }
+bool same(const GlweRef& a, const GlweRef& b) { return a.p == b.p; }
 
-// CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): chain of d
-// external products; first one reads src, the rest run in place on dst.
-void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, const double* prep, int d, int gx, int gy) {
-    for (int i = 0; i < d; i++) launch_ep(c, i == 0 ? src : dst, dst, prep + (size_t)i * fheram_ctx::GGSW, gx, gy);
-}
-// GLWE::trace(start, end) (SURVEY.md A.7): step i = rsh(1) then a += phi_{g_i}(KS(a)).
-// First step reads `in` (optionally rotated by X^-(x*rot_mul)), the rest run in place on out.
-void trace_steps(fheram_ctx* c, GlweRef in, GlweRef out, int start, int end, int gx, int gy, int rot_mul = 0) {
-    for (int i = start; i < end; i++) {
-        const bool first = (i == start);
-        KsArgs ka = ks_args(c, first ? in : out, first ? in : out, out, trace_key(c, i), c->gal[i], 0, first ? rot_mul : 0);
-        launch_ks<KS_TRACE, 3, 4, 3>(c, ka, gx, gy);
+// Runs n dependent out-of-place steps src -> ... -> dst, alternating between dst and tmp so that
+// the last step lands in dst.  step(i, in, out) launches step i.  dst may be src.
+template <typename F>
+void run_chain(fheram_ctx* c, int n, GlweRef src, GlweRef dst, GlweRef tmp, int gx, int gy, F&& step) {
+    if (n <= 0) { if (!same(src, dst)) launch_copy(c, src, dst, gx, gy); return; }
+    if (same(src, dst) && (n % 2 == 1)) {   // the first step would write what it reads: finish in tmp, copy back
+        run_chain(c, n, src, tmp, dst, gx, gy, step);
+        launch_copy(c, tmp, dst, gx, gy);
+        return;
+    }
+    GlweRef cur = src;
+    for (int i = 0; i < n; i++) {
+        GlweRef out = ((n - 1 - i) % 2 == 0) ? dst : tmp;
+        step(i, cur, out);
+        cur = out;
     }
 }
+// CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): d external products.
+void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, const double* prep, int d, int gx, int gy) {
+    run_chain(c, d, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) { launch_ep(c, in, out, prep + (size_t)i * fheram_ctx::GGSW, gx, gy); });
+}
+// GLWE::trace(start, end) (SURVEY.md A.7): step i = rsh(1) then a += phi_{g_i}(KS(a)).
+// The first step may read its input rotated by X^-(x*rot_mul) (write path, ram.rs:621,629).
+void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start, int end, int gx, int gy, int rot_mul = 0) {
+    run_chain(c, end - start, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) {
+        KsArgs ka = ks_args(c, in, in, out, trace_key(c, start + i), c->gal[start + i], 0, i == 0 ? rot_mul : 0);
+        launch_ks<KS_TRACE, 3, 4, 3>(c, ka, gx, gy);
+    });
+}
 // GLWEPacker over `count` leaves per y (ram.rs:425-448), level-synchronous:
-// leaves at src(x = row, y), ping-pong arenas A and B with the same strides as src.
+// leaves at src(x = row, y); A and B are ping-pong arenas with the same strides (src may be A).
 // Returns the arena that holds the packed result at x = 0.
 int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long sy, long sx, size_t count, int gy) {
     const int k = ilog2_ceil(count);
     const int L0 = LOGN - k;
     int32_t* cur = src;
-    if (L0 > 0) {   // levels where every leaf is alone: a <- rsh(a); a <- a + phi(a)
-        trace_steps(c, ref(src, sy, sx), ref(A, sy, sx), 0, L0, (int)count, gy);
-        cur = A;
+    auto other = [&](int32_t* x) { return x == A ? B : A; };
+    for (int i = 0; i < L0; i++) {   // levels where every leaf is alone: a <- rsh(a); a <- a + phi(a)
+        int32_t* nxt = other(cur);
+        KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i]);
+        launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)count, gy);
+        cur = nxt;
     }
     size_t live = count;
     for (int m = 0; m < k; m++) {
         const int i = L0 + m;
         const long h = (long)1 << (k - 1 - m);
-        int32_t* nxt = (cur == A) ? B : A;
+        int32_t* nxt = other(cur);
         const long n_pair = std::max<long>(0, std::min<long>(h, (long)live - h));
         const long n_alone = std::min<long>(h, (long)live) - n_pair;
         if (n_pair > 0) {
@@ -297,40 +335,40 @@ int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
     const long sy = (long)c->rows * G;
     const int ws = c->ws;
     const int R = (int)c->rows;
-    GlweRef data = ref(c->d_data, sy, G);
-    GlweRef res = ref(c->d_res, G, 0);
-    // coordinate 0
+    GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G);
+    GlweRef res = ref(c->d_res, G, 0), tmp = ref(c->d_tmp, G, 0), tree = ref(c->d_tree, G, 0);
     coordinate_prepare(c, addr, 0);                                                   // ram.rs:416-419 / 496-499
     const int d0 = (int)c->base2d[0].size();
     if (c->n2 == 1) {
+        GlweRef row0 = ref(c->d_data, sy, 0);
         if (prepare_write) {
-            ep_chain(c, ref(c->d_data, sy, 0), ref(c->d_data, sy, 0), c->d_prep, d0, 1, ws);   // ram.rs:502-504 (rows == 1)
-            HIPCHK(c, hipMemcpy2DAsync(c->d_res, G * 4, c->d_data, sy * 4, G * 4, ws, hipMemcpyDeviceToDevice, c->stream));   // ram.rs:537
+            ep_chain(c, row0, row0, ref(c->d_scrA, sy, 0), c->d_prep, d0, 1, ws);     // ram.rs:502-504 (rows == 1)
+            launch_copy(c, row0, res, 1, ws);                                         // ram.rs:537
         } else {
-            ep_chain(c, ref(c->d_data, sy, 0), ref(c->d_res, G, 0), c->d_prep, d0, 1, ws);     // ram.rs:451
+            ep_chain(c, row0, res, tmp, c->d_prep, d0, 1, ws);                        // ram.rs:451
         }
     } else {
         int32_t* leaves;
         if (prepare_write) {
-            ep_chain(c, data, data, c->d_prep, d0, R, ws);                            // ram.rs:502-504
+            ep_chain(c, data, data, A, c->d_prep, d0, R, ws);                         // ram.rs:502-504
             leaves = c->d_data;
         } else {
-            ep_chain(c, data, ref(c->d_scrA, sy, G), c->d_prep, d0, R, ws);           // ram.rs:429-434
+            ep_chain(c, data, A, B, c->d_prep, d0, R, ws);                            // ram.rs:429-434
             leaves = c->d_scrA;
         }
         int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws);   // ram.rs:435-448 / 510-521
-        // coordinate 1
+        GlweRef pk = ref(packed, sy, 0);
         coordinate_prepare(c, addr, 1);
         const int d1 = (int)c->base2d[1].size();
         if (prepare_write) {
-            HIPCHK(c, hipMemcpy2DAsync(c->d_tree, G * 4, packed, sy * 4, G * 4, ws, hipMemcpyDeviceToDevice, c->stream));   // ram.rs:525-527
-            ep_chain(c, ref(c->d_tree, G, 0), ref(c->d_tree, G, 0), c->d_prep, d1, 1, ws);                                  // ram.rs:502-504 (i = 1)
-            HIPCHK(c, hipMemcpyAsync(c->d_res, c->d_tree, (size_t)ws * G * 4, hipMemcpyDeviceToDevice, c->stream));         // ram.rs:535
+            launch_copy(c, pk, tree, 1, ws);                                          // ram.rs:525-527
+            ep_chain(c, tree, tree, tmp, c->d_prep, d1, 1, ws);                       // ram.rs:502-504 (i = 1)
+            launch_copy(c, tree, res, 1, ws);                                         // ram.rs:535
         } else {
-            ep_chain(c, ref(packed, sy, 0), res, c->d_prep, d1, 1, ws);               // ram.rs:454
+            ep_chain(c, pk, res, tmp, c->d_prep, d1, 1, ws);                          // ram.rs:454
         }
     }
-    trace_steps(c, res, res, 0, LOGN, 1, ws);                                         // ram.rs:457 / 540
+    trace_steps(c, res, res, tmp, 0, LOGN, 1, ws);                                    // ram.rs:457 / 540
     if (prepare_write) c->state = true;                                               // ram.rs:533
     return FHERAM_OK;
 }
@@ -404,15 +442,26 @@ int fheram_ctx_create(const fheram_params* p, int device, fheram_ctx** out) {
     CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CCHK(hipEventCreate(&c->t0));
     CCHK(hipEventCreate(&c->t1));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prepare), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ext_product<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_AUTO, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_TRACE, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_PAIR, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_ADD, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_SUBNEG, 3, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_AUTO, 4, 5, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keyswitch<KS_TENSOR, 4, 5, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    {
+        const char* e = getenv("FHERAM_NCO");
+        c->nco = (e && e[0] == '2') ? 2 : ((e && e[0] == '1') ? 1 : 0);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
+    }
+#define LDSATTR(k) CCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES))
+    LDSATTR(k_prepare);
+    LDSATTR((&k_ext_product<3, 4, 1>));
+    LDSATTR((&k_ext_product<3, 4, 2>));
+#define LDSATTR_KS(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>))
+    LDSATTR_KS(KS_AUTO, 3, 4, 3);
+    LDSATTR_KS(KS_TRACE, 3, 4, 3);
+    LDSATTR_KS(KS_PAIR, 3, 4, 3);
+    LDSATTR_KS(KS_ADD, 3, 4, 3);
+    LDSATTR_KS(KS_SUBNEG, 3, 4, 3);
+    LDSATTR_KS(KS_AUTO, 4, 5, 4);
+    LDSATTR_KS(KS_TENSOR, 4, 5, 4);
+#undef LDSATTR_KS
+#undef LDSATTR
 
     std::vector<double> tw = make_twiddles();
     c->ninv = centred(powmod_u((uint64_t)N, P_U64 - 2));
@@ -425,6 +474,8 @@ int fheram_ctx_create(const fheram_params* p, int device, fheram_ctx** out) {
     CCHK(hipMalloc(&c->d_data, nrow * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_scrA, nrow * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_scrB, nrow * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_scrC, nrow * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_tmp2, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tree, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_res, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tmp, (size_t)c->ws * G * sizeof(int32_t)));
@@ -445,7 +496,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_scrC, c->d_tmp2, c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -593,11 +644,11 @@ int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* ad
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     const int ws = c->ws, R = (int)c->rows;
-    GlweRef wref = ref(c->d_w, G, 0);
+    GlweRef wref = ref(c->d_w, G, 0), tmp = ref(c->d_tmp, G, 0), tmp2 = ref(c->d_tmp2, G, 0), tree = ref(c->d_tree, G, 0);
+    GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G), C = ref(c->d_scrC, sy, G);
     // write_first_step (ram.rs:544-577): t <- normalize(t - trace(t) + w)
-    GlweRef top = (c->n2 != 1) ? ref(c->d_tree, G, 0) : ref(c->d_data, sy, 0);
-    GlweRef tmp = ref(c->d_tmp, G, 0);
-    trace_steps(c, top, tmp, 0, LOGN, 1, ws);
+    GlweRef top = (c->n2 != 1) ? tree : ref(c->d_data, sy, 0);
+    trace_steps(c, top, tmp, tmp2, 0, LOGN, 1, ws);
     {
         ProfScope ps(c, "elementwise", ws);
         hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws), dim3(256), 0, c->stream, top, tmp, wref, top);
@@ -605,23 +656,22 @@ int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* ad
     if (c->n2 == 2) {
         // mid step for i = 0 (ram.rs:258-276, 579-632)
         coordinate_prepare_inv(c, addr, 1);
-        ep_chain(c, ref(c->d_tree, G, 0), ref(c->d_tree, G, 0), c->d_prep, (int)c->base2d[1].size(), 1, ws);   // ram.rs:610
-        GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G);
-        trace_steps(c, data, A, 0, LOGN, R, ws);                               // tmp_a = trace(ct_hi)              ram.rs:616
-        trace_steps(c, ref(c->d_tree, G, 0), B, 0, LOGN, R, ws, 1);            // tmp_a = trace(ct_lo * X^-row)     ram.rs:621,629
+        ep_chain(c, tree, tree, tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);   // ram.rs:610
+        trace_steps(c, data, A, C, 0, LOGN, R, ws);                                  // tmp_a = trace(ct_hi)            ram.rs:616
+        trace_steps(c, tree, B, C, 0, LOGN, R, ws, 1);                               // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
         {
             ProfScope ps(c, "elementwise", (uint64_t)R * ws);
             hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws), dim3(256), 0, c->stream, data, A, B, data);   // ram.rs:617,625-626
         }
         {   // ct_lo has been rotated `rows` times by X^-1 (ram.rs:629)
             ProfScope ps(c, "elementwise", ws);
-            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws), dim3(256), 0, c->stream, ref(c->d_tree, G, 0), tmp, -R);
+            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws), dim3(256), 0, c->stream, tree, tmp, -R);
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_tree, c->d_tmp, (size_t)ws * G * 4, hipMemcpyDeviceToDevice, c->stream));
+        launch_copy(c, tmp, tree, 1, ws);
     }
     // last step (ram.rs:278-293, 634-649)
     coordinate_prepare_inv(c, addr, 0);
-    ep_chain(c, ref(c->d_data, sy, G), ref(c->d_data, sy, G), c->d_prep, (int)c->base2d[0].size(), R, ws);
+    ep_chain(c, data, data, A, c->d_prep, (int)c->base2d[0].size(), R, ws);
     c->state = false;
     HIPCHK(c, hipGetLastError());
     return FHERAM_OK;
@@ -645,10 +695,12 @@ int fheram_glwe_external_product(fheram_ctx* c, const int64_t* a, int batch, con
     int rc = upload_i64(c, da.p, a, (size_t)batch * G);
     if (rc == FHERAM_OK) rc = upload_i64(c, dg.p, ggsw, fheram_ctx::GGSW);
     if (rc != FHERAM_OK) return rc;
+    DevBuf dout;
+    HIPCHK(c, hipMalloc(&dout.p, (size_t)batch * G * 4));
     launch_prepare(c, dg.p, c->d_prep, (int)(fheram_ctx::GGSW / N));
-    launch_ep(c, ref(da.p, 0, (long)G), ref(da.p, 0, (long)G), c->d_prep, batch, 1);
+    launch_ep(c, ref(da.p, 0, (long)G), ref(dout.p, 0, (long)G), c->d_prep, batch, 1);
     HIPCHK(c, hipGetLastError());
-    return download_i64(c, res, da.p, (size_t)batch * G);
+    return download_i64(c, res, dout.p, (size_t)batch * G);
 }
 int fheram_glwe_automorphism(fheram_ctx* c, int mode, int64_t gal_el, const int64_t* a, int batch, int64_t* res) {
     if (!c || !a || !res || batch <= 0 || mode < 0 || mode > 2) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
@@ -675,13 +727,15 @@ int fheram_glwe_trace(fheram_ctx* c, int start, int end, const int64_t* a, int b
     if (!c->keys_loaded) return fail(c, FHERAM_ERR_KEYS, "evaluation keys not loaded");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t G = fheram_ctx::GLWE;
-    DevBuf da;
+    DevBuf da, db, dc;
     HIPCHK(c, hipMalloc(&da.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&db.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&dc.p, (size_t)batch * G * 4));
     int rc = upload_i64(c, da.p, a, (size_t)batch * G);
     if (rc != FHERAM_OK) return rc;
-    trace_steps(c, ref(da.p, 0, (long)G), ref(da.p, 0, (long)G), start, end, batch, 1);
+    trace_steps(c, ref(da.p, 0, (long)G), ref(db.p, 0, (long)G), ref(dc.p, 0, (long)G), start, end, batch, 1);
     HIPCHK(c, hipGetLastError());
-    return download_i64(c, res, da.p, (size_t)batch * G);
+    return download_i64(c, res, db.p, (size_t)batch * G);
 }
 int fheram_glwe_pack(fheram_ctx* c, const int64_t* cts, int count, int64_t* out) {
     if (!c || !cts || !out || count <= 0 || count > N) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");

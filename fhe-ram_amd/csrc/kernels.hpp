@@ -1,5 +1,6 @@
-// Fused GLWE-level kernels of the FHE-RAM path for gfx950.  One workgroup (512 threads) per
-// ciphertext operation; 2-D grids: blockIdx.x = row inside a sub-RAM, blockIdx.y = sub-RAM.
+// Fused GLWE-level kernels of the FHE-RAM path for gfx950.  One or two workgroups (T = N/E threads)
+// per ciphertext operation; grids: blockIdx.x = row inside a sub-RAM, blockIdx.y = sub-RAM,
+// blockIdx.z = output column when the operation is split by column (NCO = 1).
 //
 //   k_prepare      GGSWPrepared::prepare / key prepare      (coordinate_prepared.rs:104-116, keys.rs:57-71)
 //   k_ext_product  glwe_external_product(_inplace)           (coordinate_prepared.rs:147-177)
@@ -10,7 +11,7 @@
 // Device GLWE layout: int32 [limb][col][N] (the host's int64 layout narrowed; limbs are
 // normalised to 17 bits so nothing is lost).  Prepared operands: double, transform domain,
 // scaled by 1/N, stored so that thread t's elements (2kk, 2kk+1) are one 16-byte word at
-// [kk*512 + t] (coalesced 16 B/lane loads).
+// [kk*T + t] (coalesced 16 B/lane loads).
 #pragma once
 #include "ntt_dev.hpp"
 
@@ -59,13 +60,33 @@ __device__ __forceinline__ void mac_poly(double (&acc)[E], const double (&x)[E],
     }
 }
 
+// Prepared-operand registers of one polynomial (E/2 16-byte words per thread).
+struct OpRegs { double2 v[E / 2]; };
+__device__ __forceinline__ void load_ops(OpRegs& o, const double* __restrict__ g, int tid) {
+    const double2* gp = reinterpret_cast<const double2*>(g);
+#pragma unroll
+    for (int kk = 0; kk < E / 2; kk++) o.v[kk] = gp[kk * T + tid];
+}
+__device__ __forceinline__ void mac_regs(double (&acc)[E], const double (&x)[E], const OpRegs& o) {
+#pragma unroll
+    for (int kk = 0; kk < E / 2; kk++) {
+        acc[2 * kk] = macmod(acc[2 * kk], x[2 * kk], o.v[kk].x);
+        acc[2 * kk + 1] = macmod(acc[2 * kk + 1], x[2 * kk + 1], o.v[kk].y);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // k_ext_product: res = a (x) G   (SURVEY.md A.4), SA = limbs of a and res, SG = limbs of G.
-// 2*SA forward transforms, 2*SA*2*SG pointwise MACs, 2*SG inverse transforms, SG->SA normalise.
-// In-place (res == a) is safe: a thread reads and writes only its own coefficients.
+// Phase 1: the 2*SA limb polynomials of a are transformed and stay in registers.
+// Phase 2: for each output column, the SG output limbs are produced from the least significant
+// one upwards: pointwise MAC of the 2*SA inputs against G, inverse transform, then one step of
+// the base-2^17 normalisation whose carry is the only state that survives to the next limb
+// (vec_znx_big_normalize walks the limbs in exactly this order).
+// NCO = 1: blockIdx.z selects the output column (two workgroups per ciphertext, phase 1 done by
+// both); res must then not alias a.
 // ---------------------------------------------------------------------------------------
-template <int SA, int SG>
-__global__ __launch_bounds__(T) void k_ext_product(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
+template <int SA, int SG, int NCO>
+__global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
                                                    const double* __restrict__ tw_g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
@@ -74,39 +95,57 @@ __global__ __launch_bounds__(T) void k_ext_product(GlweRef a, GlweRef res, const
     load_twiddles(tw, tw_g, tid);
     const int32_t* ap = at(a);
     int32_t* rp = at(res);
+    const int co0 = (NCO == 1) ? (int)blockIdx.z : 0;
 
-    double acc[2 * SG][E];   // [col_out * SG + limb]
+    double xh[2 * SA][E];   // [row*2 + col_in]
 #pragma unroll
-    for (int q = 0; q < 2 * SG; q++)
+    for (int in = 0; in < 2 * SA; in++) {
+        int xi[E];
 #pragma unroll
-        for (int k = 0; k < E; k++) acc[q][k] = 0.0;
-
-#pragma unroll 1
-    for (int in = 0; in < 2 * SA; in++) {   // in = row*2 + col_in  (GGSW row = limb of a)
-        const int row = in >> 1, cin = in & 1;
-        double x[E];
-        const int32_t* src = ap + glwe_off(row, cin);
+        for (int k = 0; k < E; k++) xi[k] = ap[glwe_off(in >> 1, in & 1) + tid + T * k];
 #pragma unroll
-        for (int k = 0; k < E; k++) x[k] = (double)src[tid + T * k];
-        ntt_fwd(x, tw, data, tid);
-        const double* g = ggsw + (long)in * (SG * 2) * N;   // [limb][col_out] polys of this (row, cin)
-#pragma unroll
-        for (int j = 0; j < SG; j++)
-#pragma unroll
-            for (int co = 0; co < 2; co++) mac_poly(acc[co * SG + j], x, g + (long)(j * 2 + co) * N, tid);
+        for (int k = 0; k < E; k++) xh[in][k] = (double)xi[k];
     }
 #pragma unroll
-    for (int co = 0; co < 2; co++) {
+    for (int in = 0; in < 2 * SA; in++) ntt_fwd(xh[in], tw, data, tid);
+
+#pragma unroll 1
+    for (int c = 0; c < NCO; c++) {
+        const int co = co0 + c;
+        double carry[E];
 #pragma unroll
-        for (int j = 0; j < SG; j++) ntt_inv(acc[co * SG + j], tw, data, tid);
+        for (int k = 0; k < E; k++) carry[k] = 0.0;
+        // One operand register set: the column_in 0 operands of limb j are prefetched one limb ahead
+        // (their latency hides behind the inverse transform); the column_in 1 operands are fetched
+        // in one batch between the two halves of the MAC (one exposed round trip per limb).
+        OpRegs g[SA];
 #pragma unroll
-        for (int k = 0; k < E; k++) {
-            double in_l[SG], out_l[SA];
+        for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co) * N, tid);
+#pragma unroll 1
+        for (int j = SG - 1; j >= 0; j--) {
+            double acc[E];
 #pragma unroll
-            for (int j = 0; j < SG; j++) in_l[j] = acc[co * SG + j][k];
-            normalize_coeff<SG, SA>(in_l, out_l);
+            for (int k = 0; k < E; k++) acc[k] = 0.0;
 #pragma unroll
-            for (int j = 0; j < SA; j++) rp[glwe_off(j, co) + tid + T * k] = (int)out_l[j];
+            for (int r = 0; r < SA; r++) mac_regs(acc, xh[2 * r], g[r]);
+#pragma unroll
+            for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r + 1) * SG + j) * 2 + co) * N, tid);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < SA; r++) mac_regs(acc, xh[2 * r + 1], g[r]);
+            if (j > 0) {
+#pragma unroll
+                for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (j - 1)) * 2 + co) * N, tid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ntt_inv(acc, tw, data, tid);
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const double v = acc[k] + carry[k];
+                const double cy = carry_of(v);
+                carry[k] = cy;
+                if (j < SA) rp[glwe_off(j, co) + tid + T * k] = (int)digit_of(v, cy);
+            }
         }
     }
 }
@@ -177,8 +216,17 @@ __device__ __forceinline__ void load_pair_sum(const KsArgs& ka, const int32_t* a
     rsh1_coeff<SX>(v, x);
 }
 
-template <int MODE, int SX, int SK, int SO>
-__global__ __launch_bounds__(T) void k_keyswitch(KsArgs ka) {
+__device__ __forceinline__ int sel_limb(const int (&x)[3], int j) { return j == 0 ? x[0] : (j == 1 ? x[1] : x[2]); }
+__device__ __forceinline__ int sel_limb(const int (&x)[4], int j) { return j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3])); }
+
+// Structure as k_ext_product: the SX mask limbs are transformed once and stay in registers; the
+// SK output limbs of each column are then streamed from the least significant one upwards
+// (MAC, inverse transform, body add, automorphism through LDS, post-step, one normalisation
+// step), so the live state between limbs is just the carries.
+// NCO as in k_ext_product; with NCO == 1 out must not alias a or b.  With NCO == 2 out may
+// alias a only for modes whose threads read and write the same coefficients (no rotation).
+template <int MODE, int SX, int SK, int SO, int NCO>
+__global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
@@ -188,98 +236,107 @@ __global__ __launch_bounds__(T) void k_keyswitch(KsArgs ka) {
     const int32_t* bp = (MODE == KS_PAIR) ? at(ka.b) : nullptr;
     int32_t* op = at(ka.out);
     constexpr int BODY_COL = (MODE == KS_TENSOR) ? 1 : 0;
+    const int co0 = (NCO == 1) ? (int)blockIdx.z : 0;
 
-    double acc[2 * SK][E];
+    // Phase 1: mask column of x, all limbs, transformed
+    double xh[SX][E];
 #pragma unroll
-    for (int q = 0; q < 2 * SK; q++)
+    for (int k = 0; k < E; k++) {
+        int xm[SX];
+        load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
 #pragma unroll
-        for (int k = 0; k < E; k++) acc[q][k] = 0.0;
-
-    {
-        // mask column of x at this thread's coefficients, all limbs (int32)
-        int xm[E][SX];
-#pragma unroll
-        for (int k = 0; k < E; k++) load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm[k]);
-#pragma unroll
-        for (int r = 0; r < SX; r++) {
-            double x[E];
-#pragma unroll
-            for (int k = 0; k < E; k++) x[k] = (double)xm[k][r];
-            ntt_fwd(x, tw, data, tid);
-            const double* g = ka.key + (long)r * (SK * 2) * N;
-#pragma unroll
-            for (int j = 0; j < SK; j++)
-#pragma unroll
-                for (int co = 0; co < 2; co++) mac_poly(acc[co * SK + j], x, g + (long)(j * 2 + co) * N, tid);
-        }
+        for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
     }
+#pragma unroll
+    for (int r = 0; r < SX; r++) ntt_fwd(xh[r], tw, data, tid);
 
+#pragma unroll 1
+    for (int c = 0; c < NCO; c++) {
+        const int co = co0 + c;
+        // per-coefficient limbs needed by the post-step (and the body add) of this column
+        int xa[E][SX];   // KS_TRACE/ADD/SUBNEG: x column co;  KS_PAIR: rsh1(rot(a,-t)+b) column co
+        int xb[E][SX];   // body limbs of x (column 0), only used when co == BODY_COL
 #pragma unroll
-    for (int co = 0; co < 2; co++) {
-        // inverse transforms of this output column; body add; automorphism through LDS
-        int xb[E][SX];
-        if (co == BODY_COL) {
-#pragma unroll
-            for (int k = 0; k < E; k++) load_x<MODE, SX>(ka, ap, bp, 0, tid + T * k, xb[k]);
+        for (int k = 0; k < E; k++) {
+            const int i = tid + T * k;
+            if constexpr (MODE == KS_PAIR) {
+                load_pair_sum<SX>(ka, ap, bp, co, i, xa[k]);
+                load_x<MODE, SX>(ka, ap, bp, 0, i, xb[k]);
+            } else if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) {
+                load_x<MODE, SX>(ka, ap, bp, co, i, xa[k]);   // for co == 0 this is also the body
+            } else {
+                load_x<MODE, SX>(ka, ap, bp, 0, i, xb[k]);
+            }
         }
+        double carry[E], carry2[E];
 #pragma unroll
-        for (int j = 0; j < SK; j++) {
-            double(&v)[E] = acc[co * SK + j];
-            ntt_inv(v, tw, data, tid);
-            if (co == BODY_COL && j < SX) {
+        for (int k = 0; k < E; k++) { carry[k] = 0.0; carry2[k] = 0.0; }
+
+        // key operands are prefetched one limb ahead: the loads for limb j-1 are issued right
+        // after the MAC of limb j and their latency hides behind the inverse transform
+        OpRegs g[SX];
 #pragma unroll
-                for (int k = 0; k < E; k++) v[k] += (double)xb[k][j];
+        for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + (SK - 1)) * 2 + co) * N, tid);
+#pragma unroll 1
+        for (int j = SK - 1; j >= 0; j--) {
+            double acc[E];
+#pragma unroll
+            for (int k = 0; k < E; k++) acc[k] = 0.0;
+#pragma unroll
+            for (int r = 0; r < SX; r++) mac_regs(acc, xh[r], g[r]);
+            if (j > 0) {
+#pragma unroll
+                for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ntt_inv(acc, tw, data, tid);
+            if (co == BODY_COL && j < SX) {   // vec_znx_big_add_small_inplace of the body limbs
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) acc[k] += (double)sel_limb(xa[k], j);
+                    else acc[k] += (double)sel_limb(xb[k], j);
+                }
             }
             if constexpr (MODE != KS_TENSOR) {
-                // phi_g: destination i' takes +-source i, i = i' * ginv mod 2N
+                // phi_g: destination i' takes +-source i, i = i' * ginv mod 2N (odd stride: conflict free)
                 __syncthreads();
 #pragma unroll
-                for (int k = 0; k < E; k++) data[tid + T * k] = v[k];
+                for (int k = 0; k < E; k++) data[tid + T * k] = acc[k];
                 __syncthreads();
 #pragma unroll
                 for (int k = 0; k < E; k++) {
                     int s = ((tid + T * k) * ka.ginv) & (2 * N - 1);
-                    double sg = 1.0;
-                    if (s >= N) { s -= N; sg = -1.0; }
-                    v[k] = sg * data[s];
+                    const bool ng = s >= N;
+                    if (ng) s -= N;
+                    const double d = data[s];
+                    acc[k] = ng ? -d : d;
                 }
             }
-        }
-        // post-step at destination coefficients i' = tid + 512k
+            // post-step + one normalisation step at destination coefficients i' = tid + T*k
 #pragma unroll
-        for (int k = 0; k < E; k++) {
-            const int i = tid + T * k;
-            double in_l[SK], out_l[SO];
-#pragma unroll
-            for (int j = 0; j < SK; j++) in_l[j] = acc[co * SK + j][k];
-            if constexpr (MODE == KS_TRACE || MODE == KS_ADD) {
-                int xa[SX];
-                load_x<MODE, SX>(ka, ap, bp, co, i, xa);
-#pragma unroll
-                for (int j = 0; j < SX; j++) in_l[j] += (double)xa[j];
-            } else if constexpr (MODE == KS_SUBNEG) {
-                int xa[SX];
-                load_x<MODE, SX>(ka, ap, bp, co, i, xa);
-#pragma unroll
-                for (int j = 0; j < SK; j++) in_l[j] = (j < SX ? (double)xa[j] : 0.0) - in_l[j];
-            }
-            normalize_coeff<SK, SO>(in_l, out_l);
-            if constexpr (MODE == KS_PAIR) {
-                static_assert(MODE != KS_PAIR || SO == SX, "pair needs SO == SX");
-                int a2[SX];
-                load_pair_sum<SX>(ka, ap, bp, co, i, a2);
-                double d_l[SO], r_l[SO];
-#pragma unroll
-                for (int j = 0; j < SO; j++) d_l[j] = (double)a2[j] - out_l[j];
-                normalize_coeff<SO, SO>(d_l, r_l);
-                int dst = i + ka.t;
-                const bool ng = dst >= N;
-                if (ng) dst -= N;
-#pragma unroll
-                for (int j = 0; j < SO; j++) op[glwe_off(j, co) + dst] = cneg((int)r_l[j], ng);
-            } else {
-#pragma unroll
-                for (int j = 0; j < SO; j++) op[glwe_off(j, co) + i] = (int)out_l[j];
+            for (int k = 0; k < E; k++) {
+                const int i = tid + T * k;
+                double v = acc[k];
+                if constexpr (MODE == KS_TRACE || MODE == KS_ADD) { if (j < SX) v += (double)sel_limb(xa[k], j); }
+                if constexpr (MODE == KS_SUBNEG) v = (j < SX ? (double)sel_limb(xa[k], j) : 0.0) - v;
+                v += carry[k];
+                const double cy = carry_of(v);
+                carry[k] = cy;
+                if (j < SO) {
+                    const double d = digit_of(v, cy);
+                    if constexpr (MODE == KS_PAIR) {
+                        // a <- normalize(rsh1(a*X^-t + b) - tmp); a <- a * X^t
+                        const double v2 = (double)sel_limb(xa[k], j) - d + carry2[k];
+                        const double cy2 = carry_of(v2);
+                        carry2[k] = cy2;
+                        int dst = i + ka.t;
+                        const bool ng = dst >= N;
+                        if (ng) dst -= N;
+                        op[glwe_off(j, co) + dst] = cneg((int)digit_of(v2, cy2), ng);
+                    } else {
+                        op[glwe_off(j, co) + i] = (int)d;
+                    }
+                }
             }
         }
     }
@@ -307,6 +364,13 @@ __global__ __launch_bounds__(256) void k_sub_add_norm(GlweRef a, GlweRef b, Glwe
 #pragma unroll
         for (int j = 0; j < S; j++) op[glwe_off(j, col) + i] = (int)out_l[j];
     }
+}
+// out = a   (glwe_copy, ram.rs:526,535,537)
+template <int S>
+__global__ __launch_bounds__(256) void k_copy(GlweRef a, GlweRef out) {
+    const int4* ap = reinterpret_cast<const int4*>(at(a));
+    int4* op = reinterpret_cast<int4*>(at(out));
+    for (int idx = threadIdx.x; idx < S * 2 * N / 4; idx += blockDim.x) op[idx] = ap[idx];
 }
 // out = a * X^rho   (glwe_rotate, ram.rs:629); out must not alias a
 template <int S>

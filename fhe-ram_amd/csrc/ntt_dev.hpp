@@ -22,10 +22,16 @@ namespace fk {
 
 constexpr int LOGN = 12;
 constexpr int N = 1 << LOGN;
-constexpr int E = 8;             // coefficients per thread
-constexpr int T = N / E;         // threads per workgroup (512 = 8 waves)
+#ifndef FK_LOGE
+#define FK_LOGE 4
+#endif
+constexpr int LOGE = FK_LOGE;    // log2(coefficients per thread): 3 (512 threads) or 4 (256 threads)
+static_assert(LOGN % LOGE == 0, "radix must divide log N");
+constexpr int E = 1 << LOGE;     // coefficients per thread
+constexpr int T = N / E;         // threads per workgroup
+constexpr int NPASS = LOGN / LOGE;
 constexpr int LDS_TW = N;        // doubles
-constexpr int LDS_DATA = N + N / 8;  // doubles (exchange buffer incl. padding)
+constexpr int LDS_DATA = N + N / E;  // doubles (exchange buffer incl. padding)
 constexpr size_t LDS_BYTES = (size_t)(LDS_TW + LDS_DATA) * sizeof(double);
 
 constexpr double P = 281474976768001.0;   // 2^48 + 57345, prime
@@ -55,22 +61,23 @@ __device__ __forceinline__ double reduce(double x) {
 }
 
 // ---- index patterns --------------------------------------------------------------------
-// Pass Q holds, per thread, the 8 elements  hi*8*S + k*S + lo  with S = 512 >> 3Q,
-// tid = hi*S + lo.  Pass 0 = natural coefficients tid + 512k; pass 3 = 8*tid + k.
+// Pass Q holds, per thread, the E elements  hi*E*S + k*S + lo  with S = N >> LOGE*(Q+1),
+// tid = hi*S + lo.  Pass 0 = natural coefficients tid + T*k; the last pass = E*tid + k.
 template <int Q>
 __device__ __forceinline__ int pat(int tid, int k) {
-    constexpr int LS = 9 - 3 * Q;  // log2(S)
+    constexpr int LS = LOGN - LOGE * (Q + 1);  // log2(S)
     const int hi = tid >> LS;
     const int lo = tid & ((1 << LS) - 1);
-    return (hi << (LS + 3)) + (k << LS) + lo;
+    return (hi << (LS + LOGE)) + (k << LS) + lo;
 }
-// LDS layout of exchange X (between pass X and X+1): pad R per 8R block when the read runs
-// (R = 64, 8, 1) are shorter than a 32-lane group, so both sides are bank-conflict free.
+// LDS layout of exchange X (between pass X and X+1).  The read side walks runs of
+// R = N >> LOGE*(X+2) consecutive elements; when R < 32 a pad of R per E*R block keeps both the
+// write side and the read side bank-conflict free.
 template <int X>
 __device__ __forceinline__ int lay(int idx) {
-    if constexpr (X == 0) return idx;
-    else if constexpr (X == 1) return idx + ((idx >> 6) << 3);
-    else return idx + (idx >> 3);
+    constexpr int LR = LOGN - LOGE * (X + 2);  // log2(R)
+    if constexpr (LR >= 5) return idx;
+    else return idx + ((idx >> (LR + LOGE)) << LR);
 }
 
 template <int X>
@@ -106,77 +113,78 @@ __device__ __forceinline__ void gs(double& a, double& b, double w) {
     b = mulmod(d, w);
 }
 
-// Twiddle table position of W[2^s + J] (s = 3Q + u, J = hi*2^u + j): 2^s + j*8^Q + hi.
+// Twiddle table position of W[2^s + J] (s = LOGE*Q + u, J = hi*2^u + j): 2^s + j*E^Q + hi, so
+// the lanes of a wave read consecutive (last pass) or identical (first passes) addresses.
 template <int Q>
 __device__ __forceinline__ void fwd_pass(double (&x)[E], const double* tw, int tid) {
-    constexpr int LS = 9 - 3 * Q;
-    constexpr int HQ = 1 << (3 * Q);
+    constexpr int LS = LOGN - LOGE * (Q + 1);
+    constexpr int HQ = 1 << (LOGE * Q);
     const int hi = tid >> LS;
-    {
-        const double w = tw[HQ + hi];
-        bf(x[0], x[4], w); bf(x[1], x[5], w); bf(x[2], x[6], w); bf(x[3], x[7], w);
-    }
-    {
-        const double w0 = tw[2 * HQ + hi], w1 = tw[2 * HQ + HQ + hi];
-        bf(x[0], x[2], w0); bf(x[1], x[3], w0); bf(x[4], x[6], w1); bf(x[5], x[7], w1);
-    }
-    {
-        const double w0 = tw[4 * HQ + hi], w1 = tw[4 * HQ + HQ + hi], w2 = tw[4 * HQ + 2 * HQ + hi], w3 = tw[4 * HQ + 3 * HQ + hi];
-        bf(x[0], x[1], w0); bf(x[2], x[3], w1); bf(x[4], x[5], w2); bf(x[6], x[7], w3);
+#pragma unroll
+    for (int u = 0; u < LOGE; u++) {
+        const int half = E >> (u + 1);
+#pragma unroll
+        for (int j = 0; j < (1 << u); j++) {
+            const double w = tw[(HQ << u) + j * HQ + hi];
+#pragma unroll
+            for (int i = 0; i < half; i++) bf(x[2 * j * half + i], x[2 * j * half + i + half], w);
+        }
     }
 }
-// inverse of fwd_pass<Q> up to the factor 8 (the total 1/N is folded into prepared operands):
+// inverse of fwd_pass<Q> up to the factor E (the total 1/N is folded into prepared operands):
 // w^-1 of forward twiddle W[m + J] is -W[2m - 1 - J]; the sign is absorbed by using (b - a).
 template <int Q>
 __device__ __forceinline__ void inv_pass(double (&x)[E], const double* tw, int tid) {
-    constexpr int LS = 9 - 3 * Q;
-    constexpr int HQ = 1 << (3 * Q);
+    constexpr int LS = LOGN - LOGE * (Q + 1);
+    constexpr int HQ = 1 << (LOGE * Q);
     const int hm = HQ - 1 - (tid >> LS);
-    {
-        const double w0 = tw[4 * HQ + 3 * HQ + hm], w1 = tw[4 * HQ + 2 * HQ + hm], w2 = tw[4 * HQ + HQ + hm], w3 = tw[4 * HQ + hm];
-        gs(x[0], x[1], w0); gs(x[2], x[3], w1); gs(x[4], x[5], w2); gs(x[6], x[7], w3);
-    }
-    {
-        const double w0 = tw[2 * HQ + HQ + hm], w1 = tw[2 * HQ + hm];
-        gs(x[0], x[2], w0); gs(x[1], x[3], w0); gs(x[4], x[6], w1); gs(x[5], x[7], w1);
-    }
-    {
-        const double w = tw[HQ + hm];
-        gs(x[0], x[4], w); gs(x[1], x[5], w); gs(x[2], x[6], w); gs(x[3], x[7], w);
+#pragma unroll
+    for (int u = LOGE - 1; u >= 0; u--) {
+        const int half = E >> (u + 1);
+#pragma unroll
+        for (int j = 0; j < (1 << u); j++) {
+            const double w = tw[(HQ << u) + ((1 << u) - 1 - j) * HQ + hm];
+#pragma unroll
+            for (int i = 0; i < half; i++) gs(x[2 * j * half + i], x[2 * j * half + i + half], w);
+        }
     }
 }
 
-// Forward negacyclic NTT.  in: x[k] = coefficient tid + 512k (|x| < 2^20).
-// out: x[k] = transform value at position 8*tid + k (bit-reversed order), |x| < 8p.
-__device__ __forceinline__ void ntt_fwd(double (&x)[E], const double* tw, double* data, int tid) {
-    fwd_pass<0>(x, tw, tid);
-    exchange_fwd<0>(x, data, tid);
-    fwd_pass<1>(x, tw, tid);
+template <int Q>
+__device__ __forceinline__ void fwd_rec(double (&x)[E], const double* tw, double* data, int tid) {
+    fwd_pass<Q>(x, tw, tid);
+    if constexpr (Q + 1 < NPASS) {
+        // values grow by < p per stage; pull them back before they reach ~8p
+        if constexpr (((Q + 1) * LOGE) % 6 == 0 || LOGE >= 4) {
 #pragma unroll
-    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
-    exchange_fwd<1>(x, data, tid);
-    fwd_pass<2>(x, tw, tid);
-    exchange_fwd<2>(x, data, tid);
-    fwd_pass<3>(x, tw, tid);
+            for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+        }
+        exchange_fwd<Q>(x, data, tid);
+        fwd_rec<Q + 1>(x, tw, data, tid);
+    }
 }
-// Inverse negacyclic NTT without the 1/N factor.  in: x[k] at position 8*tid + k, |x| < 16p.
-// out: x[k] = N * coefficient(tid + 512k) mod p, centred in [-p/2, p/2].
+template <int Q>
+__device__ __forceinline__ void inv_rec(double (&x)[E], const double* tw, double* data, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+    inv_pass<Q>(x, tw, tid);
+    if constexpr (Q > 0) {
+        exchange_inv<Q - 1>(x, data, tid);
+        inv_rec<Q - 1>(x, tw, data, tid);
+    }
+}
+
+// Forward negacyclic NTT.  in: x[k] = coefficient tid + T*k (|x| < 2^20).
+// out: x[k] = transform value at position E*tid + k (bit-reversed order), |x| < 8p.
+__device__ __forceinline__ void ntt_fwd(double (&x)[E], const double* tw, double* data, int tid) {
+    fwd_rec<0>(x, tw, data, tid);
+}
+// Inverse negacyclic NTT without the 1/N factor.  in: x[k] at position E*tid + k, |x| < 16p.
+// out: x[k] = N * coefficient(tid + T*k) mod p, centred in [-p/2, p/2].
+// A Gentleman-Sande pass of LOGE stages multiplies magnitudes by up to E, hence the reduce()
+// at the head of every pass (LOGE = 4: 0.5p -> 8p, inside the exactness window of mulmod).
 __device__ __forceinline__ void ntt_inv(double (&x)[E], const double* tw, double* data, int tid) {
-#pragma unroll
-    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
-    inv_pass<3>(x, tw, tid);
-    exchange_inv<2>(x, data, tid);
-#pragma unroll
-    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
-    inv_pass<2>(x, tw, tid);
-    exchange_inv<1>(x, data, tid);
-#pragma unroll
-    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
-    inv_pass<1>(x, tw, tid);
-    exchange_inv<0>(x, data, tid);
-#pragma unroll
-    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
-    inv_pass<0>(x, tw, tid);
+    inv_rec<NPASS - 1>(x, tw, data, tid);
 #pragma unroll
     for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
 }
