@@ -14,6 +14,7 @@
 // [kk*T + t] (coalesced 16 B/lane loads).
 #pragma once
 #include "ntt_dev.hpp"
+#include <type_traits>
 
 namespace fk {
 
@@ -35,16 +36,16 @@ __global__ __launch_bounds__(T) void k_prepare(const int32_t* __restrict__ in, d
     const int tid = threadIdx.x;
     load_twiddles(tw, tw_g, tid);
     const int32_t* src = in + (long)blockIdx.x * N;
-    double x[E];
+    double x[1][E];
 #pragma unroll
-    for (int k = 0; k < E; k++) x[k] = (double)src[tid + T * k];
-    ntt_fwd(x, tw, data, tid);
+    for (int k = 0; k < E; k++) x[0][k] = (double)src[tid + T * k];
+    ntt_fwd<1>(x, tw, data, tid);
     double2* o = reinterpret_cast<double2*>(out + (long)blockIdx.x * N);
 #pragma unroll
     for (int kk = 0; kk < E / 2; kk++) {
         double2 v;
-        v.x = reduce(mulmod(reduce(x[2 * kk]), ninv));
-        v.y = reduce(mulmod(reduce(x[2 * kk + 1]), ninv));
+        v.x = reduce(mulmod(reduce(x[0][2 * kk]), ninv));
+        v.y = reduce(mulmod(reduce(x[0][2 * kk + 1]), ninv));
         o[kk * T + tid] = v;
     }
 }
@@ -77,17 +78,55 @@ __device__ __forceinline__ void mac_regs(double (&acc)[E], const double (&x)[E],
 
 // ---------------------------------------------------------------------------------------
 // k_ext_product: res = a (x) G   (SURVEY.md A.4), SA = limbs of a and res, SG = limbs of G.
-// Phase 1: the 2*SA limb polynomials of a are transformed and stay in registers.
+// Phase 1: the 2*SA limb polynomials of a are transformed (SA at a time) and stay in registers.
 // Phase 2: for each output column, the SG output limbs are produced from the least significant
-// one upwards: pointwise MAC of the 2*SA inputs against G, inverse transform, then one step of
-// the base-2^17 normalisation whose carry is the only state that survives to the next limb
-// (vec_znx_big_normalize walks the limbs in exactly this order).
+// one upwards, two at a time: pointwise MAC of the 2*SA inputs against G, a paired inverse
+// transform, then the base-2^17 normalisation steps whose carry is the only state that survives
+// to the next limbs (vec_znx_big_normalize walks the limbs in exactly this order).
 // NCO = 1: blockIdx.z selects the output column (two workgroups per ciphertext, phase 1 done by
-// both); res must then not alias a.
+// both).  res must not alias a.
 // ---------------------------------------------------------------------------------------
+// Batch sizes of the transforms (tuning knobs): BF polynomials per forward NTT call, BI per inverse.
+#ifndef FK_BF
+#define FK_BF 3
+#endif
+#ifndef FK_BI
+#define FK_BI 1
+#endif
+constexpr int BF = FK_BF, BI = FK_BI;
+static_assert(BF <= BMAX && BI <= BMAX, "LDS holds BMAX exchange buffers");
+
+// forward transform of S polynomials, BF at a time
+template <int S, int R = 0>
+__device__ __forceinline__ void fwd_all(double (&x)[S][E], const double* tw, double* data, int tid) {
+    if constexpr (R < S) {
+        constexpr int C = (S - R < BF) ? (S - R) : BF;
+        ntt_fwd<C>(*reinterpret_cast<double(*)[C][E]>(&x[R]), tw, data, tid);
+        fwd_all<S, R + C>(x, tw, data, tid);
+    }
+}
+
+template <int SA, int SG>
+__device__ __forceinline__ void ep_mac(double (&acc)[E], const double (&x0)[SA][E], const double (&x1)[SA][E], OpRegs (&g)[SA],
+                                       const double* __restrict__ ggsw, int j, int co, int jnext, int tid) {
+    // g holds the column_in 0 operands of limb j on entry and those of limb jnext on exit
+#pragma unroll
+    for (int r = 0; r < SA; r++) mac_regs(acc, x0[r], g[r]);
+#pragma unroll
+    for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r + 1) * SG + j) * 2 + co) * N, tid);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < SA; r++) mac_regs(acc, x1[r], g[r]);
+    if (jnext >= 0) {
+#pragma unroll
+        for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + jnext) * 2 + co) * N, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int SA, int SG, int NCO>
 __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
-                                                   const double* __restrict__ tw_g) {
+                                                            const double* __restrict__ tw_g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
@@ -97,17 +136,28 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
     int32_t* rp = at(res);
     const int co0 = (NCO == 1) ? (int)blockIdx.z : 0;
 
-    double xh[2 * SA][E];   // [row*2 + col_in]
+    double x0[SA][E], x1[SA][E];   // limbs of column 0 / column 1 of a
+    {
+        int xi[SA][E];
 #pragma unroll
-    for (int in = 0; in < 2 * SA; in++) {
-        int xi[E];
+        for (int r = 0; r < SA; r++)
 #pragma unroll
-        for (int k = 0; k < E; k++) xi[k] = ap[glwe_off(in >> 1, in & 1) + tid + T * k];
+            for (int k = 0; k < E; k++) xi[r][k] = ap[glwe_off(r, 0) + tid + T * k];
 #pragma unroll
-        for (int k = 0; k < E; k++) xh[in][k] = (double)xi[k];
+        for (int r = 0; r < SA; r++)
+#pragma unroll
+            for (int k = 0; k < E; k++) x0[r][k] = (double)xi[r][k];
+#pragma unroll
+        for (int r = 0; r < SA; r++)
+#pragma unroll
+            for (int k = 0; k < E; k++) xi[r][k] = ap[glwe_off(r, 1) + tid + T * k];
+        fwd_all<SA>(x0, tw, data, tid);
+#pragma unroll
+        for (int r = 0; r < SA; r++)
+#pragma unroll
+            for (int k = 0; k < E; k++) x1[r][k] = (double)xi[r][k];
+        fwd_all<SA>(x1, tw, data, tid);
     }
-#pragma unroll
-    for (int in = 0; in < 2 * SA; in++) ntt_fwd(xh[in], tw, data, tid);
 
 #pragma unroll 1
     for (int c = 0; c < NCO; c++) {
@@ -115,37 +165,40 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
         double carry[E];
 #pragma unroll
         for (int k = 0; k < E; k++) carry[k] = 0.0;
-        // One operand register set: the column_in 0 operands of limb j are prefetched one limb ahead
-        // (their latency hides behind the inverse transform); the column_in 1 operands are fetched
-        // in one batch between the two halves of the MAC (one exposed round trip per limb).
         OpRegs g[SA];
 #pragma unroll
         for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co) * N, tid);
-#pragma unroll 1
-        for (int j = SG - 1; j >= 0; j--) {
-            double acc[E];
-#pragma unroll
-            for (int k = 0; k < E; k++) acc[k] = 0.0;
-#pragma unroll
-            for (int r = 0; r < SA; r++) mac_regs(acc, xh[2 * r], g[r]);
-#pragma unroll
-            for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r + 1) * SG + j) * 2 + co) * N, tid);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < SA; r++) mac_regs(acc, xh[2 * r + 1], g[r]);
-            if (j > 0) {
-#pragma unroll
-                for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (j - 1)) * 2 + co) * N, tid);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ntt_inv(acc, tw, data, tid);
+
+        auto emit = [&](const double (&v_)[E], int j) {
 #pragma unroll
             for (int k = 0; k < E; k++) {
-                const double v = acc[k] + carry[k];
+                const double v = v_[k] + carry[k];
                 const double cy = carry_of(v);
                 carry[k] = cy;
                 if (j < SA) rp[glwe_off(j, co) + tid + T * k] = (int)digit_of(v, cy);
             }
+        };
+        constexpr int REM = SG % BI;   // limbs left over for a final narrower batch
+#pragma unroll 1
+        for (int j = SG - 1; j >= BI - 1 + REM; j -= BI) {
+            double acc[BI][E];
+#pragma unroll
+            for (int b = 0; b < BI; b++) {
+#pragma unroll
+                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
+                ep_mac<SA, SG>(acc[b], x0, x1, g, ggsw, j - b, co, j - b - 1, tid);
+            }
+            ntt_inv<BI>(acc, tw, data, tid);
+#pragma unroll
+            for (int b = 0; b < BI; b++) emit(acc[b], j - b);
+        }
+        if constexpr (REM == 1) {
+            double acc[1][E];
+#pragma unroll
+            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+            ep_mac<SA, SG>(acc[0], x0, x1, g, ggsw, 0, co, -1, tid);
+            ntt_inv<1>(acc, tw, data, tid);
+            emit(acc[0], 0);
         }
     }
 }
@@ -219,12 +272,11 @@ __device__ __forceinline__ void load_pair_sum(const KsArgs& ka, const int32_t* a
 __device__ __forceinline__ int sel_limb(const int (&x)[3], int j) { return j == 0 ? x[0] : (j == 1 ? x[1] : x[2]); }
 __device__ __forceinline__ int sel_limb(const int (&x)[4], int j) { return j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3])); }
 
-// Structure as k_ext_product: the SX mask limbs are transformed once and stay in registers; the
-// SK output limbs of each column are then streamed from the least significant one upwards
-// (MAC, inverse transform, body add, automorphism through LDS, post-step, one normalisation
-// step), so the live state between limbs is just the carries.
-// NCO as in k_ext_product; with NCO == 1 out must not alias a or b.  With NCO == 2 out may
-// alias a only for modes whose threads read and write the same coefficients (no rotation).
+// Structure as k_ext_product: the SX mask limbs are transformed together and stay in registers; the
+// SK output limbs of each column are then streamed from the least significant one upwards, two at
+// a time (MAC, paired inverse transform, body add, automorphism through LDS, post-step and one
+// normalisation step each), so the live state between limbs is just the carries.
+// NCO as in k_ext_product.  out must not alias a or b.
 template <int MODE, int SX, int SK, int SO, int NCO>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -247,8 +299,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll
         for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
     }
-#pragma unroll
-    for (int r = 0; r < SX; r++) ntt_fwd(xh[r], tw, data, tid);
+    fwd_all<SX>(xh, tw, data, tid);
 
 #pragma unroll 1
     for (int c = 0; c < NCO; c++) {
@@ -272,47 +323,33 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll
         for (int k = 0; k < E; k++) { carry[k] = 0.0; carry2[k] = 0.0; }
 
-        // key operands are prefetched one limb ahead: the loads for limb j-1 are issued right
-        // after the MAC of limb j and their latency hides behind the inverse transform
+        // key operands are prefetched one step ahead: the loads for the next limb are issued right
+        // after a MAC and their latency hides behind the following MAC / inverse transform
         OpRegs g[SX];
+        auto fetch = [&](int j) {
 #pragma unroll
-        for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + (SK - 1)) * 2 + co) * N, tid);
-#pragma unroll 1
-        for (int j = SK - 1; j >= 0; j--) {
-            double acc[E];
+            for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
+        };
+        auto mac = [&](double (&acc)[E], int jnext) {
 #pragma unroll
             for (int k = 0; k < E; k++) acc[k] = 0.0;
 #pragma unroll
             for (int r = 0; r < SX; r++) mac_regs(acc, xh[r], g[r]);
-            if (j > 0) {
-#pragma unroll
-                for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
-            }
+            if (jnext >= 0) fetch(jnext);
             __builtin_amdgcn_sched_barrier(0);
-            ntt_inv(acc, tw, data, tid);
-            if (co == BODY_COL && j < SX) {   // vec_znx_big_add_small_inplace of the body limbs
+        };
+        // vec_znx_big_add_small_inplace of the body limbs (source coefficients)
+        auto add_body = [&](double (&acc)[E], int j) {
+            if (co == BODY_COL && j < SX) {
 #pragma unroll
                 for (int k = 0; k < E; k++) {
                     if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) acc[k] += (double)sel_limb(xa[k], j);
                     else acc[k] += (double)sel_limb(xb[k], j);
                 }
             }
-            if constexpr (MODE != KS_TENSOR) {
-                // phi_g: destination i' takes +-source i, i = i' * ginv mod 2N (odd stride: conflict free)
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < E; k++) data[tid + T * k] = acc[k];
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    int s = ((tid + T * k) * ka.ginv) & (2 * N - 1);
-                    const bool ng = s >= N;
-                    if (ng) s -= N;
-                    const double d = data[s];
-                    acc[k] = ng ? -d : d;
-                }
-            }
-            // post-step + one normalisation step at destination coefficients i' = tid + T*k
+        };
+        // post-step + one normalisation step at destination coefficients i' = tid + T*k
+        auto emit = [&](const double (&acc)[E], int j) {
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 const int i = tid + T * k;
@@ -338,6 +375,51 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
                     }
                 }
             }
+        };
+
+        // phi_g: destination i' takes +-source i, i = i' * ginv mod 2N (odd stride: conflict free)
+        auto permute = [&](auto& acc, auto nb) {
+            constexpr int NB = decltype(nb)::value;
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int k = 0; k < E; k++) data[b * LDS_DATA + tid + T * k] = acc[b][k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                int s = ((tid + T * k) * ka.ginv) & (2 * N - 1);
+                const bool ng = s >= N;
+                if (ng) s -= N;
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const double d = data[b * LDS_DATA + s];
+                    acc[b][k] = ng ? -d : d;
+                }
+            }
+        };
+
+        constexpr int REM = SK % BI;
+        fetch(SK - 1);
+#pragma unroll 1
+        for (int j = SK - 1; j >= BI - 1 + REM; j -= BI) {
+            double acc[BI][E];
+#pragma unroll
+            for (int b = 0; b < BI; b++) mac(acc[b], j - b - 1);
+            ntt_inv<BI>(acc, tw, data, tid);
+#pragma unroll
+            for (int b = 0; b < BI; b++) add_body(acc[b], j - b);
+            if constexpr (MODE != KS_TENSOR) permute(acc, std::integral_constant<int, BI>{});
+#pragma unroll
+            for (int b = 0; b < BI; b++) emit(acc[b], j - b);
+        }
+        if constexpr (REM == 1) {
+            double acc[1][E];
+            mac(acc[0], -1);
+            ntt_inv<1>(acc, tw, data, tid);
+            add_body(acc[0], 0);
+            if constexpr (MODE != KS_TENSOR) permute(acc, std::integral_constant<int, 1>{});
+            emit(acc[0], 0);
         }
     }
 }

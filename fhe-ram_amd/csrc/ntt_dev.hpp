@@ -23,7 +23,7 @@ namespace fk {
 constexpr int LOGN = 12;
 constexpr int N = 1 << LOGN;
 #ifndef FK_LOGE
-#define FK_LOGE 4
+#define FK_LOGE 3
 #endif
 constexpr int LOGE = FK_LOGE;    // log2(coefficients per thread): 3 (512 threads) or 4 (256 threads)
 static_assert(LOGN % LOGE == 0, "radix must divide log N");
@@ -32,7 +32,8 @@ constexpr int T = N / E;         // threads per workgroup
 constexpr int NPASS = LOGN / LOGE;
 constexpr int LDS_TW = N;        // doubles
 constexpr int LDS_DATA = N + N / E;  // doubles (exchange buffer incl. padding)
-constexpr size_t LDS_BYTES = (size_t)(LDS_TW + LDS_DATA) * sizeof(double);
+constexpr int BMAX = 3;          // polynomials transformed together (3 exchange buffers fit 160 KB of LDS)
+constexpr size_t LDS_BYTES = (size_t)(LDS_TW + BMAX * LDS_DATA) * sizeof(double);
 
 constexpr double P = 281474976768001.0;   // 2^48 + 57345, prime
 constexpr double PINV = 1.0 / 281474976768001.0;
@@ -80,23 +81,33 @@ __device__ __forceinline__ int lay(int idx) {
     else return idx + ((idx >> (LR + LOGE)) << LR);
 }
 
-template <int X>
-__device__ __forceinline__ void exchange_fwd(double (&x)[E], double* data, int tid) {
+// B polynomials are transformed together: one LDS exchange (two barriers) moves all of them, and
+// the B independent butterfly streams give the FP64 pipe the ILP that 2 waves/SIMD cannot.
+template <int X, int B>
+__device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, int tid) {
     __syncthreads();  // previous readers of the buffer are done
 #pragma unroll
-    for (int k = 0; k < E; k++) data[lay<X>(pat<X>(tid, k))] = x[k];
+    for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X>(tid, k))] = x[b][k];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < E; k++) x[k] = data[lay<X>(pat<X + 1>(tid, k))];
+    for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) x[b][k] = data[b * LDS_DATA + lay<X>(pat<X + 1>(tid, k))];
 }
-template <int X>
-__device__ __forceinline__ void exchange_inv(double (&x)[E], double* data, int tid) {
+template <int X, int B>
+__device__ __forceinline__ void exchange_inv(double (&x)[B][E], double* data, int tid) {
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < E; k++) data[lay<X>(pat<X + 1>(tid, k))] = x[k];
+    for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X + 1>(tid, k))] = x[b][k];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < E; k++) x[k] = data[lay<X>(pat<X>(tid, k))];
+    for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) x[b][k] = data[b * LDS_DATA + lay<X>(pat<X>(tid, k))];
 }
 
 // Cooley-Tukey butterfly: (x, y) <- (x + w*y, x - w*y)
@@ -150,43 +161,53 @@ __device__ __forceinline__ void inv_pass(double (&x)[E], const double* tw, int t
     }
 }
 
-template <int Q>
-__device__ __forceinline__ void fwd_rec(double (&x)[E], const double* tw, double* data, int tid) {
-    fwd_pass<Q>(x, tw, tid);
+template <int Q, int B>
+__device__ __forceinline__ void fwd_rec(double (&x)[B][E], const double* tw, double* data, int tid) {
+#pragma unroll
+    for (int b = 0; b < B; b++) fwd_pass<Q>(x[b], tw, tid);
     if constexpr (Q + 1 < NPASS) {
         // values grow by < p per stage; pull them back before they reach ~8p
         if constexpr (((Q + 1) * LOGE) % 6 == 0 || LOGE >= 4) {
 #pragma unroll
-            for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+            for (int b = 0; b < B; b++)
+#pragma unroll
+                for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
         }
-        exchange_fwd<Q>(x, data, tid);
-        fwd_rec<Q + 1>(x, tw, data, tid);
+        exchange_fwd<Q, B>(x, data, tid);
+        fwd_rec<Q + 1, B>(x, tw, data, tid);
     }
 }
-template <int Q>
-__device__ __forceinline__ void inv_rec(double (&x)[E], const double* tw, double* data, int tid) {
+template <int Q, int B>
+__device__ __forceinline__ void inv_rec(double (&x)[B][E], const double* tw, double* data, int tid) {
 #pragma unroll
-    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
-    inv_pass<Q>(x, tw, tid);
+    for (int b = 0; b < B; b++) {
+#pragma unroll
+        for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+        inv_pass<Q>(x[b], tw, tid);
+    }
     if constexpr (Q > 0) {
-        exchange_inv<Q - 1>(x, data, tid);
-        inv_rec<Q - 1>(x, tw, data, tid);
+        exchange_inv<Q - 1, B>(x, data, tid);
+        inv_rec<Q - 1, B>(x, tw, data, tid);
     }
 }
 
-// Forward negacyclic NTT.  in: x[k] = coefficient tid + T*k (|x| < 2^20).
-// out: x[k] = transform value at position E*tid + k (bit-reversed order), |x| < 8p.
-__device__ __forceinline__ void ntt_fwd(double (&x)[E], const double* tw, double* data, int tid) {
-    fwd_rec<0>(x, tw, data, tid);
+// Forward negacyclic NTT of B polynomials.  in: x[b][k] = coefficient tid + T*k (|x| < 2^20).
+// out: x[b][k] = transform value at position E*tid + k (bit-reversed order), |x| < 8p.
+template <int B>
+__device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, double* data, int tid) {
+    fwd_rec<0, B>(x, tw, data, tid);
 }
-// Inverse negacyclic NTT without the 1/N factor.  in: x[k] at position E*tid + k, |x| < 16p.
-// out: x[k] = N * coefficient(tid + T*k) mod p, centred in [-p/2, p/2].
+// Inverse negacyclic NTT without the 1/N factor.  in: x[b][k] at position E*tid + k, |x| < 16p.
+// out: x[b][k] = N * coefficient(tid + T*k) mod p, centred in [-p/2, p/2].
 // A Gentleman-Sande pass of LOGE stages multiplies magnitudes by up to E, hence the reduce()
 // at the head of every pass (LOGE = 4: 0.5p -> 8p, inside the exactness window of mulmod).
-__device__ __forceinline__ void ntt_inv(double (&x)[E], const double* tw, double* data, int tid) {
-    inv_rec<NPASS - 1>(x, tw, data, tid);
+template <int B>
+__device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, double* data, int tid) {
+    inv_rec<NPASS - 1, B>(x, tw, data, tid);
 #pragma unroll
-    for (int k = 0; k < E; k++) x[k] = reduce(x[k]);
+    for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
 }
 
 // copy the 4096-entry twiddle table into LDS
