@@ -802,6 +802,14 @@ int fheram_profile_get(fheram_ctx* c, const char* cls, uint64_t* launches, uint6
     if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
     return FHERAM_OK;
 }
+#ifdef FK_STAMP
+// diagnostic build only: not part of include/fheram.h
+int fheram_debug_stamps(fheram_ctx* c, unsigned long long* out, int n) {
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n > 64 ? 64 : n)) == hipSuccess ? 0 : 7;
+}
+#endif
 int fheram_device_info(const fheram_ctx* c, char* name, size_t name_len, int* cus) {
     if (!c) return FHERAM_ERR_INVALID_ARG;
     hipDeviceProp_t prop;

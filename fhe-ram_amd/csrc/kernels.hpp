@@ -18,6 +18,24 @@
 
 namespace fk {
 
+// Diagnostic build only (-DFK_STAMP): s_memtime stamps of workgroup (0,0,0), lane 0, written to a
+// buffer nothing else reads.  Never compiled into the shipped library.
+#ifdef FK_STAMP
+__device__ unsigned long long g_stamps[64];
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {           \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            g_stamps[i] = t_;                                                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 struct GlweRef {   // p + y*sy + x*sx  (int32 elements)
     int32_t* p;
     long sy, sx;
@@ -283,7 +301,9 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = threadIdx.x;
+    STAMP(0);
     load_twiddles(tw, ka.tw, tid);
+    STAMP(1);
     const int32_t* ap = at(ka.a);
     const int32_t* bp = (MODE == KS_PAIR) ? at(ka.b) : nullptr;
     int32_t* op = at(ka.out);
@@ -299,7 +319,9 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll
         for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
     }
+    STAMP(2);
     fwd_all<SX>(xh, tw, data, tid);
+    STAMP(3);
 
 #pragma unroll 1
     for (int c = 0; c < NCO; c++) {
@@ -380,39 +402,47 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
         // phi_g: destination i' takes +-source i, i = i' * ginv mod 2N (odd stride: conflict free)
         auto permute = [&](auto& acc, auto nb) {
             constexpr int NB = decltype(nb)::value;
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
                 for (int k = 0; k < E; k++) data[b * LDS_DATA + tid + T * k] = acc[b][k];
-            __syncthreads();
+            lds_barrier();
+            int sidx = (tid * ka.ginv) & (2 * N - 1);
+            const int sstep = (T * ka.ginv) & (2 * N - 1);
 #pragma unroll
             for (int k = 0; k < E; k++) {
-                int s = ((tid + T * k) * ka.ginv) & (2 * N - 1);
-                const bool ng = s >= N;
-                if (ng) s -= N;
+                const bool ng = sidx >= N;
+                const int s = sidx & (N - 1);
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
                     const double d = data[b * LDS_DATA + s];
                     acc[b][k] = ng ? -d : d;
                 }
+                sidx = (sidx + sstep) & (2 * N - 1);
             }
         };
 
         constexpr int REM = SK % BI;
+        STAMP(4);
         fetch(SK - 1);
 #pragma unroll 1
         for (int j = SK - 1; j >= BI - 1 + REM; j -= BI) {
             double acc[BI][E];
+            STAMP(8 + 4 * (SK - 1 - j));
 #pragma unroll
             for (int b = 0; b < BI; b++) mac(acc[b], j - b - 1);
+            STAMP(9 + 4 * (SK - 1 - j));
             ntt_inv<BI>(acc, tw, data, tid);
+            STAMP(10 + 4 * (SK - 1 - j));
 #pragma unroll
             for (int b = 0; b < BI; b++) add_body(acc[b], j - b);
             if constexpr (MODE != KS_TENSOR) permute(acc, std::integral_constant<int, BI>{});
+            STAMP(11 + 4 * (SK - 1 - j));
 #pragma unroll
             for (int b = 0; b < BI; b++) emit(acc[b], j - b);
         }
+        STAMP(5);
         if constexpr (REM == 1) {
             double acc[1][E];
             mac(acc[0], -1);

@@ -83,14 +83,21 @@ __device__ __forceinline__ int lay(int idx) {
 
 // B polynomials are transformed together: one LDS exchange (two barriers) moves all of them, and
 // the B independent butterfly streams give the FP64 pipe the ILP that 2 waves/SIMD cannot.
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) and then
+// synchronises, but leaves global loads/stores in flight.  __syncthreads() also drains vmcnt,
+// which would serialise the operand prefetches and the output stores behind every exchange.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int X, int B>
 __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, int tid) {
-    __syncthreads();  // previous readers of the buffer are done
+    lds_barrier();  // previous readers of the buffer are done
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X>(tid, k))] = x[b][k];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
@@ -98,12 +105,12 @@ __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, in
 }
 template <int X, int B>
 __device__ __forceinline__ void exchange_inv(double (&x)[B][E], double* data, int tid) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X + 1>(tid, k))] = x[b][k];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
@@ -161,13 +168,22 @@ __device__ __forceinline__ void inv_pass(double (&x)[E], const double* tw, int t
     }
 }
 
+// Magnitude bookkeeping (all values are exact integers, so the only requirements are |v| < 2^53 =
+// 32p for every intermediate and |d*w| < 2^101 for every product):
+//  * forward (Cooley-Tukey): a stage maps (x, y) to x +- w*y with |w*y mod p| <= 0.5p + |y|*2^-3.4,
+//    so magnitudes grow by at most 0.9p per stage and stay below 11p after the 12 stages
+//    starting from limb inputs (< 2^18): no reduce() is needed for LOGE <= 3.
+//  * inverse (Gentleman-Sande): a pass of LOGE stages turns inputs bounded by I into
+//    [E*I, 4p, 2p, 2p, p, ...] (slot 0 is the sum of all E inputs, slot 1 a sum of products);
+//    after the LDS exchange all E values of a thread come from the same slot, so I is uniform per
+//    thread.  Reducing slots 0 and 1 after each pass keeps I <= 2p, the next slot 0 below
+//    E*2p = 16p < 32p and every difference that feeds a product below 16p.
 template <int Q, int B>
 __device__ __forceinline__ void fwd_rec(double (&x)[B][E], const double* tw, double* data, int tid) {
 #pragma unroll
     for (int b = 0; b < B; b++) fwd_pass<Q>(x[b], tw, tid);
     if constexpr (Q + 1 < NPASS) {
-        // values grow by < p per stage; pull them back before they reach ~8p
-        if constexpr (((Q + 1) * LOGE) % 6 == 0 || LOGE >= 4) {
+        if constexpr (LOGE >= 4) {   // radix 16: a pass adds up to 3.6p; keep the classic per-pass reduce
 #pragma unroll
             for (int b = 0; b < B; b++)
 #pragma unroll
@@ -180,29 +196,37 @@ __device__ __forceinline__ void fwd_rec(double (&x)[B][E], const double* tw, dou
 template <int Q, int B>
 __device__ __forceinline__ void inv_rec(double (&x)[B][E], const double* tw, double* data, int tid) {
 #pragma unroll
-    for (int b = 0; b < B; b++) {
-#pragma unroll
-        for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
-        inv_pass<Q>(x[b], tw, tid);
-    }
+    for (int b = 0; b < B; b++) inv_pass<Q>(x[b], tw, tid);
     if constexpr (Q > 0) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if constexpr (LOGE <= 3) {
+                x[b][0] = reduce(x[b][0]);
+                x[b][1] = reduce(x[b][1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+            }
+        }
         exchange_inv<Q - 1, B>(x, data, tid);
         inv_rec<Q - 1, B>(x, tw, data, tid);
     }
 }
 
 // Forward negacyclic NTT of B polynomials.  in: x[b][k] = coefficient tid + T*k (|x| < 2^20).
-// out: x[b][k] = transform value at position E*tid + k (bit-reversed order), |x| < 8p.
+// out: x[b][k] = transform value at position E*tid + k (bit-reversed order), |x| < 11p.
 template <int B>
 __device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, double* data, int tid) {
     fwd_rec<0, B>(x, tw, data, tid);
 }
 // Inverse negacyclic NTT without the 1/N factor.  in: x[b][k] at position E*tid + k, |x| < 16p.
 // out: x[b][k] = N * coefficient(tid + T*k) mod p, centred in [-p/2, p/2].
-// A Gentleman-Sande pass of LOGE stages multiplies magnitudes by up to E, hence the reduce()
-// at the head of every pass (LOGE = 4: 0.5p -> 8p, inside the exactness window of mulmod).
 template <int B>
 __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, double* data, int tid) {
+#pragma unroll
+    for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
     inv_rec<NPASS - 1, B>(x, tw, data, tid);
 #pragma unroll
     for (int b = 0; b < B; b++)

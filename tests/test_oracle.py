@@ -1,0 +1,201 @@
+"""CPU tests of the oracle (the checker itself): committed golden vectors, algebraic properties of
+the limb arithmetic, and the reference's functional contract
+(/root/reference/examples/fhe-ram.rs:97-176) at several sizes."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int64).tobytes()).hexdigest()
+
+
+def replay(po, params, inp):
+    """Runs the example flow from recorded inputs; returns the outputs dict."""
+    o = po.Oracle(params)
+    evk = {k: np.ascontiguousarray(inp[k]) for k in ("gal_els", "atk_glwe", "atk_ggsw_inv", "tsk")}
+    keys = o.keys_prepare(evk)
+    addr = o.address_new(np.ascontiguousarray(inp["addr"]))
+    ram = o.ram_new()
+    ram.load(np.ascontiguousarray(inp["rows"]))
+    out = {"read": ram.read(addr, keys), "rpw": ram.read_prepare_write(addr, keys), "rows_after_rpw": ram.store()}
+    t = ram.tree(0)
+    if t is not None:
+        out["tree_after_rpw"] = t
+    ram.write(np.ascontiguousarray(inp["w"]), addr, keys)
+    out["rows_after_write"] = ram.store()
+    out["readback"] = ram.read(addr, keys)
+    return o, out
+
+
+@pytest.mark.parametrize("n", [16, 64])
+def test_golden_flow_small_n(po, n):
+    z = np.load(os.path.join(GOLD, f"flow_n{n}.npz"))
+    meta = z["meta"]
+    params = po.OParams(log_n=int(meta[0]), max_addr=int(meta[1]), word_size=int(meta[2]), decomp_n=[int(x) for x in meta[4:]])
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    o, out = replay(po, params, inp)
+    for k in z.files:
+        if k.startswith("out_"):
+            assert np.array_equal(out[k[4:]], z[k]), k
+    # setup side is reproducible from the recorded seed as well
+    seed = int(meta[3])
+    assert np.array_equal(o.secret_gen(seed), inp["sk"])
+    assert np.array_equal(o.evk_gen(inp["sk"], seed + 1, seed + 2)["atk_glwe"], inp["atk_glwe"])
+
+
+@pytest.mark.parametrize("max_addr", [1 << 12, 1 << 14])
+def test_golden_digests_n4096(po, max_addr):
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden
+    d = json.load(open(os.path.join(GOLD, "digests_n4096.json")))[str(max_addr)]
+    inp, out, o = make_golden.flow(po.OParams(max_addr=max_addr, word_size=d["word_size"]), d["seed"])
+    assert {k: sha(v) for k, v in inp.items()} == d["inputs"]
+    assert {k: sha(v) for k, v in out.items()} == d["outputs"]
+    assert o.max_big() < 1 << 47                      # exact below the HIP prime / 2
+
+
+def test_znx_known_answers(po):
+    kat = json.load(open(os.path.join(GOLD, "znx_kat.json")))
+    o = po.Oracle(po.OParams(log_n=4, max_addr=16, decomp_n=[2, 2]))
+    for c in kat["cases"]:
+        a = np.array(c["in"], dtype=np.int64)
+        if c["op"] == "big_normalize":
+            got = o.big_normalize(a, c["res_size"])
+        elif c["op"] == "glwe_rsh":
+            got = o.glwe_rsh(c["k"], a)
+        elif c["op"] == "glwe_rotate":
+            got = o.glwe_rotate(c["k"], a)
+        else:
+            got = o.poly_automorphism(c["g"], a)
+        assert np.array_equal(got, np.array(c["out"], dtype=np.int64)), c["op"]
+
+
+def value_of(limbs, base2k=17):
+    """Integer sum_j x_j 2^(base2k (size-1-j)) per coefficient (python ints)."""
+    size = limbs.shape[0]
+    return [sum(int(limbs[j, i]) << (base2k * (size - 1 - j)) for j in range(size)) for i in range(limbs.shape[1])]
+
+
+def test_normalize_preserves_value_and_range(po):
+    o = po.Oracle(po.OParams(log_n=4, max_addr=16, decomp_n=[2, 2]))
+    rng = np.random.default_rng(1)
+    a = rng.integers(-(1 << 47), 1 << 47, size=(4, 16), dtype=np.int64)
+    r = o.big_normalize(a, 4)
+    assert r.min() >= -(1 << 16) and r.max() < (1 << 16)
+    mod = 1 << (17 * 4)
+    assert [x % mod for x in value_of(r)] == [x % mod for x in value_of(a)]
+    # dropping the last limb rounds to nearest (carry only)
+    r3 = o.big_normalize(a, 3)
+    for v4, v3 in zip(value_of(r), value_of(r3)):
+        assert ((v4 - (v3 << 17)) + (1 << 16)) % (1 << (17 * 4)) < (1 << 17) or abs((v4 - (v3 << 17)) % mod) <= (1 << 16)
+    # normalising a normalised vector is the identity
+    assert np.array_equal(o.big_normalize(r, 4), r)
+
+
+def test_rsh1_is_exact_halving_with_round_half_up(po):
+    o = po.Oracle(po.OParams(log_n=4, max_addr=16, decomp_n=[2, 2]))
+    rng = np.random.default_rng(2)
+    g = rng.integers(-(1 << 17), 1 << 17, size=3 * 2 * 16, dtype=np.int64)
+    out = o.glwe_rsh(1, g)
+    assert out.min() >= -(1 << 16) and out.max() < (1 << 16)          # output is normalised
+    mod = 1 << 51
+    gi, oi = g.reshape(3, 2, 16), out.reshape(3, 2, 16)
+    for col in range(2):
+        for x, y in zip(value_of(gi[:, col]), value_of(oi[:, col])):
+            assert (y - (-(-x // 2))) % mod == 0                       # ceil(x/2) mod 2^51
+
+
+def test_rotate_and_automorphism_algebra(po):
+    o = po.Oracle(po.OParams(log_n=4, max_addr=16, decomp_n=[2, 2]))
+    rng = np.random.default_rng(3)
+    g = rng.integers(-(1 << 16), 1 << 16, size=3 * 2 * 16, dtype=np.int64)
+    assert np.array_equal(o.glwe_rotate(-5, o.glwe_rotate(5, g)), g)
+    assert np.array_equal(o.glwe_rotate(16, g), -g)                    # X^N = -1
+    assert np.array_equal(o.glwe_rotate(32, g), g)
+    a = rng.integers(-9, 9, size=16, dtype=np.int64)
+    b = rng.integers(-9, 9, size=16, dtype=np.int64)
+    for gal in (-1, 5, 25):
+        lhs = o.poly_automorphism(gal, po.Oracle.negacyclic_schoolbook(a, b))
+        rhs = po.Oracle.negacyclic_schoolbook(o.poly_automorphism(gal, a), o.poly_automorphism(gal, b))
+        assert np.array_equal(lhs, rhs)                                # phi is a ring automorphism
+    assert np.array_equal(o.poly_automorphism(-1, o.poly_automorphism(-1, a)), a)
+
+
+@pytest.mark.parametrize("log_n", [4, 6, 8, 12])
+def test_ntt_matches_schoolbook(po, log_n):
+    o = po.Oracle(po.OParams(log_n=log_n, max_addr=1 << log_n, decomp_n=[log_n // 2, log_n - log_n // 2]))
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    a = rng.integers(-(1 << 16), 1 << 16, size=n, dtype=np.int64)
+    b = rng.integers(-(1 << 16), 1 << 16, size=n, dtype=np.int64)
+    if log_n == 12:
+        a[:] = -(1 << 16)
+        b[:] = -(1 << 16)                                              # worst case magnitude N * 2^32
+    assert np.array_equal(o.negacyclic_ntt(a, b), po.Oracle.negacyclic_schoolbook(a, b))
+
+
+def test_galois_elements(po):
+    assert [int(po.lib().fo_galois_element(12, i)) for i in range(12)] == \
+        [-1, 5, 25, 625, 5601, 4033, 3969, 7937, 7681, 7169, 6145, 4097]
+    from _pkg import load_package
+    assert load_package().galois_elements(12) == [-1, 5, 25, 625, 5601, 4033, 3969, 7937, 7681, 7169, 6145, 4097]
+
+
+def test_cast_u8_to_signed(po):  # examples/fhe-ram.rs:25-32
+    f = po.Oracle.cast_u8_to_signed
+    assert f(0xFF, 8) == -1 and f(0x7F, 8) == 127 and f(0x80, 8) == -128
+    assert f(7, 3) == -1 and f(3, 3) == 3 and f(4, 3) == -4 and f(0xF8 | 2, 3) == 2
+
+
+def test_op_counts_match_survey_appendix_b(po):
+    """EP / KS counts per op follow from the reference's control flow."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden
+    p = po.OParams(max_addr=1 << 14, word_size=4)
+    o = po.Oracle(p)
+    sk = o.secret_gen(1)
+    keys = o.keys_prepare(o.evk_gen(sk, 2, 3))
+    rows = o.ram_encrypt(np.zeros(p.max_addr * 4, dtype=np.uint8), sk, 4, 5)
+    addr = o.address_new(o.address_encrypt(12345, sk, 6, 7))
+    ram = o.ram_new()
+    ram.load(rows)
+    o.reset_stats()
+    ram.read(addr, keys)
+    assert (o.counters()["ep"], o.counters()["ks"]) == (68, 220)
+    o.reset_stats()
+    ram.read_prepare_write(addr, keys)
+    assert (o.counters()["ep"], o.counters()["ks"]) == (68, 220)
+    o.reset_stats()
+    ram.write(rows[:, 0], addr, keys)
+    assert (o.counters()["ep"], o.counters()["ks"]) == (68, 432 + 30)
+
+
+def test_state_machine_and_size_asserts(po):  # ram.rs:393-396,555-558,243; coordinate_prepared.rs:134
+    p = po.OParams(log_n=4, max_addr=1 << 6, decomp_n=[2, 2], word_size=2)
+    o = po.Oracle(p)
+    sk = o.secret_gen(1)
+    evk = o.evk_gen(sk, 2, 3)
+    keys = o.keys_prepare(evk)
+    rows = o.ram_encrypt(np.arange(128, dtype=np.uint8), sk, 4, 5)
+    addr = o.address_new(o.address_encrypt(9, sk, 6, 7))
+    ram = o.ram_new()
+    with pytest.raises(po.OracleError, match="unitialized memory"):
+        ram.read(addr, keys)
+    ram.load(rows)
+    with pytest.raises(po.OracleError, match="requires calling Memory.read_prepare_write"):
+        ram.write(rows[:, 0], addr, keys)
+    ram.read_prepare_write(addr, keys)
+    with pytest.raises(po.OracleError, match="requires calling Memory.write"):
+        ram.read(addr, keys)
+    with pytest.raises(po.OracleError):
+        ram.write(rows[:1, 0], addr, keys)
+    with pytest.raises(po.OracleError, match="max_addr"):
+        o.ram_encrypt(np.arange(64, dtype=np.uint8), sk, 4, 5)

@@ -1,0 +1,32 @@
+"""Diagnostic: per-phase cycle stamps of one key-switch workgroup (needs the -DFK_STAMP build)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from _pkg import load_package
+pkg = load_package()
+N = 4096
+rng = np.random.default_rng(0)
+synth = lambda shape: rng.integers(-(1 << 16), 1 << 16, size=shape, dtype=np.int64)
+ram = pkg.Ram.new_from_ram_params(4, [3, 3, 3, 3], 1 << 18)
+keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(synth((12, 3 * 4 * 2 * N))), synth(4 * 5 * 2 * N), synth(4 * 5 * 2 * N))
+L = pkg.library()
+L.fheram_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+def probe(batch, label):
+    a = synth((batch, ram.params.glwe_len()))
+    for _ in range(3):
+        ram.glwe_trace(keys, 3, 4, a)      # one trace step = one k_keyswitch<KS_TRACE> launch
+    st = (C.c_uint64 * 64)()
+    L.fheram_debug_stamps(ram._h, st, 64)
+    s = [int(x) for x in st]
+    t0 = s[0]
+    print(f"== {label}: batch {batch}")
+    names = {0: "start", 1: "twiddles in LDS", 2: "x loaded (+rsh)", 3: "forward NTT x3 done", 4: "post-step limbs loaded", 5: "column done"}
+    for i in (0, 1, 2, 3, 4):
+        print(f"  {names[i]:28s} {s[i]-t0:8d} cyc")
+    for q in range(4):
+        b = 8 + 4 * q
+        print(f"  limb {3-q}: mac {s[b+1]-s[b]:6d}  inv-ntt {s[b+2]-s[b+1]:6d}  body+permute {s[b+3]-s[b+2]:6d}  | start {s[b]-t0}")
+    print(f"  {names[5]:28s} {s[5]-t0:8d} cyc")
+os.environ.setdefault("FHERAM_NCO", "0")
+probe(4, "tail (NCO=1, 8 workgroups)")
+probe(256, "full (NCO=2, 256 workgroups)")
