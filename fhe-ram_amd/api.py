@@ -73,6 +73,12 @@ _SYMBOLS = [
     ("fheram_word_stage", C.c_int, [C.c_void_p, I64P, C.c_int]),
     ("fheram_result_download", C.c_int, [C.c_void_p, I64P]),
     ("fheram_sync", C.c_int, [C.c_void_p]),
+    ("fheram_ctx_create_sharded", C.c_int, [C.POINTER(_CParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("fheram_shard_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    ("fheram_read_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    ("fheram_read_finish", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, I64P]),
+    ("fheram_write_root", C.c_int, [C.c_void_p, I64P, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    ("fheram_write_shard", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("fheram_glwe_external_product", C.c_int, [C.c_void_p, I64P, C.c_int, I64P, I64P]),
     ("fheram_glwe_automorphism", C.c_int, [C.c_void_p, C.c_int, C.c_int64, I64P, C.c_int, I64P]),
     ("fheram_glwe_trace", C.c_int, [C.c_void_p, C.c_int, C.c_int, I64P, C.c_int, I64P]),
@@ -265,13 +271,16 @@ class _AddrHandle:
 class Ram:
     """ram.rs:25-29.  Owns the device-resident sub-RAMs, tree, packer scratch and prepared keys."""
 
-    def __init__(self, params: Optional[Parameters] = None, device: int = 0):
+    def __init__(self, params: Optional[Parameters] = None, device: int = 0, shard: int = 0, n_shards: int = 1):
+        """shard / n_shards: row sharding across GPUs; this context then owns rows
+        r = shard (mod n_shards) of every sub-RAM and only the *_partial / *_root / *_shard ops apply."""
         self.params = params or Parameters.new()
+        self.shard, self.n_shards = int(shard), int(n_shards)
         self._h = None
         L = library()
         out = C.c_void_p()
         cp = self.params._c()
-        rc = L.fheram_ctx_create(C.byref(cp), device, C.byref(out))
+        rc = L.fheram_ctx_create_sharded(C.byref(cp), device, self.shard, self.n_shards, C.byref(out))
         if rc != 0:
             raise FheRamError(rc, L.fheram_last_error(None).decode())
         self._h = out.value
@@ -307,16 +316,20 @@ class Ram:
         return np.zeros((self.params.word_size(), self.params.glwe_len()), dtype=np.int64)
 
     # -- data hand-over (Ram::encrypt_sk output, ram.rs:129-167)
+    def local_rows(self) -> int:
+        return self.params.rows() // self.n_shards
+
     def load_encrypted(self, rows: np.ndarray):
+        """rows: [word_size][rows][GLWE]; a sharded context takes its own rows (rows[:, shard::n_shards])."""
         p = self.params
         rows = _i64(rows)
-        if rows.size != p.word_size() * p.rows() * p.glwe_len():
-            raise FheRamError(1, f"invalid data: expected {p.word_size()}x{p.rows()} GLWE rows (ram.rs:144-155)")
+        if rows.size != p.word_size() * self.local_rows() * p.glwe_len():
+            raise FheRamError(1, f"invalid data: expected {p.word_size()}x{self.local_rows()} GLWE rows (ram.rs:144-155)")
         self._chk(library().fheram_ram_upload(self._h, _p(rows)))
 
     def store_encrypted(self) -> np.ndarray:
         p = self.params
-        rows = np.zeros((p.word_size(), p.rows(), p.glwe_len()), dtype=np.int64)
+        rows = np.zeros((p.word_size(), self.local_rows(), p.glwe_len()), dtype=np.int64)
         self._chk(library().fheram_ram_download(self._h, _p(rows)))
         return rows
 
@@ -350,6 +363,46 @@ class Ram:
         w = _i64(w)
         n_w = w.shape[0] if w.ndim > 1 else w.size // self.params.glwe_len()
         self._chk(library().fheram_write(self._h, _p(w), n_w, address._device(self)))
+
+    # -- row-sharded path (every buffer: host int64 ndarray, or (device_ptr, True) for an int32 device buffer)
+    @staticmethod
+    def _buf(b):
+        if isinstance(b, tuple):
+            return C.c_void_p(int(b[0])), 1
+        return b.ctypes.data_as(C.c_void_p), 0
+
+    def read_partial(self, address: Address, keys: EvaluationKeysPrepared, prepare_write: bool = False, out=None):
+        self._use_keys(keys)
+        if out is None:
+            out = self._out()
+        ptr, dev = self._buf(out)
+        self._chk(library().fheram_read_partial(self._h, address._device(self), int(prepare_write), ptr, dev))
+        return out
+
+    def read_finish(self, address: Address, keys: EvaluationKeysPrepared, partials, prepare_write: bool = False, download: bool = True):
+        self._use_keys(keys)
+        if not isinstance(partials, tuple):
+            partials = _i64(partials)
+        ptr, dev = self._buf(partials)
+        out = self._out() if download else None
+        self._chk(library().fheram_read_finish(self._h, address._device(self), int(prepare_write), ptr, dev, _p(out) if download else None))
+        return out
+
+    def write_root(self, w, address: Address, keys: EvaluationKeysPrepared, out=None):
+        self._use_keys(keys)
+        if out is None:
+            out = self._out()
+        ptr, dev = self._buf(out)
+        wp = None if w is None else _p(_i64(w))
+        self._chk(library().fheram_write_root(self._h, wp, self.params.word_size(), address._device(self), ptr, dev))
+        return out
+
+    def write_shard(self, address: Address, keys: EvaluationKeysPrepared, ct_lo):
+        self._use_keys(keys)
+        if not isinstance(ct_lo, tuple):
+            ct_lo = _i64(ct_lo)
+        ptr, dev = self._buf(ct_lo)
+        self._chk(library().fheram_write_shard(self._h, address._device(self), ptr, dev))
 
     def stage_words(self, w):
         w = _i64(w)

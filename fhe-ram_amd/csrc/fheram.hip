@@ -58,7 +58,9 @@ struct fheram_ctx {
     hipStream_t stream = nullptr;
     // derived
     int ws = 0, n2 = 0, n_digits = 0;
-    size_t rows = 0;
+    size_t rows = 0;        // GLWE rows per sub-RAM held by THIS context (all of them unless sharded)
+    size_t rows_glob = 0;   // rows per sub-RAM of the whole RAM
+    int shard = 0, n_shards = 1;   // row sharding: this context owns rows r = shard (mod n_shards)
     std::vector<std::vector<int>> base2d;
     static constexpr int S_CT = 3, S_ADDR = 4, S_EVK = 4, S_INV = 5, DNUM_CT = 3, DNUM_GGSW = 4;
     static constexpr size_t GLWE = (size_t)S_CT * 2 * N;                   // elements of a ct
@@ -83,6 +85,8 @@ struct fheram_ctx {
     int32_t* d_tmp = nullptr;      // [ws]
     int32_t* d_tmp2 = nullptr;     // [ws]
     int32_t* d_w = nullptr;        // [ws]
+    int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo
+    int32_t* d_gat[3] = {nullptr, nullptr, nullptr};   // [n_shards][ws] gathered partials + ping-pong (root)
     int nco = 0;                   // output columns per workgroup: 1 = split by column (2 workgroups per
                                    // ciphertext), 2 = one workgroup, 0 = choose per launch from the batch size
     int cus = 256;
@@ -225,10 +229,10 @@ void launch_copy(fheram_ctx* c, GlweRef src, GlweRef dst, int gx, int gy) {
     ProfScope ps(c, "elementwise", (uint64_t)gx * gy);
     hipLaunchKernelGGL((k_copy<3>), dim3(gx, gy), dim3(256), 0, c->stream, src, dst);
 }
-KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* key, int64_t gal, int t = 0, int rot_mul = 0) {
+KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* key, int64_t gal, int t = 0, int rot_mul = 0, int rot_base = 0) {
     KsArgs ka;
     ka.a = a; ka.b = b; ka.out = out; ka.key = key; ka.tw = c->d_tw;
-    ka.g = galois_mod(gal); ka.ginv = galois_inv_mod(ka.g); ka.t = t; ka.rot_mul = rot_mul;
+    ka.g = galois_mod(gal); ka.ginv = galois_inv_mod(ka.g); ka.t = t; ka.rot_mul = rot_mul; ka.rot_base = rot_base;
     return ka;
 }
 const double* trace_key(fheram_ctx* c, int i) { return c->d_atk + (size_t)i * fheram_ctx::ATK; }
@@ -257,21 +261,26 @@ void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, const double
 }
 // GLWE::trace(start, end): step i = rsh(1) then a += phi_{g_i}(KS(a)).
 // The first step may read its input rotated by X^-(x*rot_mul) (write path, ram.rs:621,629).
-void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start, int end, int gx, int gy, int rot_mul = 0) {
+void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start, int end, int gx, int gy, int rot_mul = 0, int rot_base = 0) {
     run_chain(c, end - start, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) {
-        KsArgs ka = ks_args(c, in, in, out, trace_key(c, start + i), c->gal[start + i], 0, i == 0 ? rot_mul : 0);
+        KsArgs ka = ks_args(c, in, in, out, trace_key(c, start + i), c->gal[start + i], 0, i == 0 ? rot_mul : 0, i == 0 ? rot_base : 0);
         launch_ks<KS_TRACE, 3, 4, 3>(c, ka, gx, gy);
     });
 }
-// GLWEPacker over `count` leaves per y (ram.rs:425-448), level-synchronous:
-// leaves at src(x = row, y); A and B are ping-pong arenas with the same strides (src may be A).
+// GLWEPacker (ram.rs:425-448), level-synchronous, over `count` leaves per y at
+// src(x, y); A and B are ping-pong arenas with the same strides (src may be A).
+//   n_alone    : packer levels 0..n_alone-1 in which every leaf is alone (a <- rsh(a); a <- a + phi(a))
+//   first_pair : packer level of the first pairing step; level first_pair + m joins x with x + count/2^(m+1)
+// Whole RAM: n_alone = first_pair = log N - ceil(log2 rows).  Row-sharded RAM: the shards run the
+// levels that stay inside one residue class (same n_alone / first_pair, count = local rows) and the
+// root finishes with n_alone = 0, first_pair = log N - log2(n_shards) over the gathered partials.
 // Returns the arena that holds the packed result at x = 0.
-int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long sy, long sx, size_t count, int gy) {
+int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long sy, long sx, size_t count, int gy,
+                     int n_alone, int first_pair) {
     const int k = ilog2_ceil(count);
-    const int L0 = LOGN - k;
     int32_t* cur = src;
     auto other = [&](int32_t* x) { return x == A ? B : A; };
-    for (int i = 0; i < L0; i++) {   // levels where every leaf is alone: a <- rsh(a); a <- a + phi(a)
+    for (int i = 0; i < n_alone; i++) {
         int32_t* nxt = other(cur);
         KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i]);
         launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)count, gy);
@@ -279,18 +288,18 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
     }
     size_t live = count;
     for (int m = 0; m < k; m++) {
-        const int i = L0 + m;
+        const int i = first_pair + m;
         const long h = (long)1 << (k - 1 - m);
         int32_t* nxt = other(cur);
         const long n_pair = std::max<long>(0, std::min<long>(h, (long)live - h));
-        const long n_alone = std::min<long>(h, (long)live) - n_pair;
+        const long n_alone_here = std::min<long>(h, (long)live) - n_pair;
         if (n_pair > 0) {
             KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur + h * sx, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i], N >> (i + 1));
             launch_ks<KS_PAIR, 3, 4, 3>(c, ka, (int)n_pair, gy);
         }
-        if (n_alone > 0) {
+        if (n_alone_here > 0) {
             KsArgs ka = ks_args(c, ref(cur + n_pair * sx, sy, sx), ref(cur, sy, sx), ref(nxt + n_pair * sx, sy, sx), trace_key(c, i), c->gal[i]);
-            launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)n_alone, gy);
+            launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)n_alone_here, gy);
         }
         live = std::min<size_t>(live, (size_t)h);
         cur = nxt;
@@ -328,36 +337,58 @@ int check_common(fheram_ctx* c, const fheram_addr* addr) {
     return FHERAM_OK;
 }
 
-// Shared body of SubRam::read (ram.rs:382-459) and SubRam::read_prepare_write (ram.rs:461-542)
-// for all sub-RAMs at once.  Result left in d_res.
-int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
+// SubRam::read (ram.rs:382-459) / SubRam::read_prepare_write (ram.rs:461-542) for all sub-RAMs at
+// once, in two stages so that a row-sharded RAM can exchange between them.
+// Stage 1 (every shard): coordinate-0 products on the local rows + the packing levels that stay
+// inside the shard.  Leaves one GLWE per sub-RAM in d_part.
+int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     const int ws = c->ws;
     const int R = (int)c->rows;
     GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G);
-    GlweRef res = ref(c->d_res, G, 0), tmp = ref(c->d_tmp, G, 0), tree = ref(c->d_tree, G, 0);
+    GlweRef part = ref(c->d_part, G, 0);
     coordinate_prepare(c, addr, 0);                                                   // ram.rs:416-419 / 496-499
     const int d0 = (int)c->base2d[0].size();
     if (c->n2 == 1) {
         GlweRef row0 = ref(c->d_data, sy, 0);
         if (prepare_write) {
             ep_chain(c, row0, row0, ref(c->d_scrA, sy, 0), c->d_prep, d0, 1, ws);     // ram.rs:502-504 (rows == 1)
-            launch_copy(c, row0, res, 1, ws);                                         // ram.rs:537
+            launch_copy(c, row0, part, 1, ws);
         } else {
-            ep_chain(c, row0, res, tmp, c->d_prep, d0, 1, ws);                        // ram.rs:451
+            ep_chain(c, row0, part, ref(c->d_tmp, G, 0), c->d_prep, d0, 1, ws);       // ram.rs:451
         }
+        return FHERAM_OK;
+    }
+    int32_t* leaves;
+    if (prepare_write) {
+        ep_chain(c, data, data, A, c->d_prep, d0, R, ws);                             // ram.rs:502-504
+        leaves = c->d_data;
     } else {
-        int32_t* leaves;
-        if (prepare_write) {
-            ep_chain(c, data, data, A, c->d_prep, d0, R, ws);                         // ram.rs:502-504
-            leaves = c->d_data;
-        } else {
-            ep_chain(c, data, A, B, c->d_prep, d0, R, ws);                            // ram.rs:429-434
-            leaves = c->d_scrA;
+        ep_chain(c, data, A, B, c->d_prep, d0, R, ws);                                // ram.rs:429-434
+        leaves = c->d_scrA;
+    }
+    const int L0 = LOGN - ilog2_ceil(c->rows_glob);
+    int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws, L0, L0);   // ram.rs:435-448 / 510-521
+    launch_copy(c, ref(packed, sy, 0), part, 1, ws);
+    return FHERAM_OK;
+}
+// Stage 2 (root / unsharded): remaining packing levels over the shards' partials (`gathered`:
+// [n_shards][ws] GLWEs, or nullptr when the RAM is not sharded and the packed rows are in d_part),
+// coordinate-1 products and the final trace.  Result left in d_res.
+int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t* gathered) {
+    const long G = (long)fheram_ctx::GLWE;
+    const int ws = c->ws;
+    GlweRef res = ref(c->d_res, G, 0), tmp = ref(c->d_tmp, G, 0), tree = ref(c->d_tree, G, 0);
+    GlweRef pk = ref(c->d_part, G, 0);
+    if (c->n2 == 2) {
+        if (gathered) {
+            const int kG = ilog2_ceil((size_t)c->n_shards);
+            int32_t* a0 = c->d_gat[1];   // gathered partials live in d_gat[0]
+            int32_t* a1 = c->d_gat[2];
+            int32_t* packed = pack_levels(c, gathered, a0, a1, G, (long)ws * G, (size_t)c->n_shards, ws, 0, LOGN - kG);
+            pk = ref(packed, G, 0);
         }
-        int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws);   // ram.rs:435-448 / 510-521
-        GlweRef pk = ref(packed, sy, 0);
         coordinate_prepare(c, addr, 1);
         const int d1 = (int)c->base2d[1].size();
         if (prepare_write) {
@@ -367,9 +398,62 @@ int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
         } else {
             ep_chain(c, pk, res, tmp, c->d_prep, d1, 1, ws);                          // ram.rs:454
         }
+    } else {
+        launch_copy(c, pk, res, 1, ws);                                               // ram.rs:452 / 537
     }
     trace_steps(c, res, res, tmp, 0, LOGN, 1, ws);                                    // ram.rs:457 / 540
-    if (prepare_write) c->state = true;                                               // ram.rs:533
+    return FHERAM_OK;
+}
+int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
+    int rc = read_local(c, addr, prepare_write);
+    if (rc != FHERAM_OK) return rc;
+    rc = read_top(c, addr, prepare_write, nullptr);
+    if (rc == FHERAM_OK && prepare_write) c->state = true;                            // ram.rs:533
+    return rc;
+}
+
+// Ram::write (ram.rs:226-294) in two stages.
+// Stage 1 (root / unsharded): write_first_step on the top of the tree and, for n2 == 2, the inverse
+// coordinate-1 products: leaves the un-rotated ct_lo of every sub-RAM in d_part.
+int write_top(fheram_ctx* c, const fheram_addr* addr) {
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    const int ws = c->ws;
+    GlweRef wref = ref(c->d_w, G, 0), tmp = ref(c->d_tmp, G, 0), tmp2 = ref(c->d_tmp2, G, 0), tree = ref(c->d_tree, G, 0);
+    // write_first_step (ram.rs:544-577): t <- normalize(t - trace(t) + w)
+    GlweRef top = (c->n2 != 1) ? tree : ref(c->d_data, sy, 0);
+    trace_steps(c, top, tmp, tmp2, 0, LOGN, 1, ws);
+    {
+        ProfScope ps(c, "elementwise", ws);
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws), dim3(256), 0, c->stream, top, tmp, wref, top);
+    }
+    if (c->n2 == 2) {
+        coordinate_prepare_inv(c, addr, 1);                                           // ram.rs:260-271
+        ep_chain(c, tree, tree, tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);     // ram.rs:610
+        launch_copy(c, tree, ref(c->d_part, G, 0), 1, ws);
+        {   // ct_lo ends up rotated `rows` times by X^-1 (ram.rs:629)
+            ProfScope ps(c, "elementwise", ws);
+            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws), dim3(256), 0, c->stream, tree, tmp, -(int)c->rows_glob);
+        }
+        launch_copy(c, tmp, tree, 1, ws);
+    }
+    return FHERAM_OK;
+}
+// Stage 2 (every shard): write_mid_step on the local rows given ct_lo (in d_part), then write_last_step.
+int write_rows(fheram_ctx* c, const fheram_addr* addr) {
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    const int ws = c->ws, R = (int)c->rows;
+    GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G), C = ref(c->d_scrC, sy, G);
+    if (c->n2 == 2) {
+        trace_steps(c, data, A, C, 0, LOGN, R, ws);                                            // tmp_a = trace(ct_hi)            ram.rs:616
+        trace_steps(c, ref(c->d_part, G, 0), B, C, 0, LOGN, R, ws, c->n_shards, c->shard);     // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
+        ProfScope ps(c, "elementwise", (uint64_t)R * ws);
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws), dim3(256), 0, c->stream, data, A, B, data);   // ram.rs:617,625-626
+    }
+    coordinate_prepare_inv(c, addr, 0);                                                        // ram.rs:278-289
+    ep_chain(c, data, data, A, c->d_prep, (int)c->base2d[0].size(), R, ws);                    // ram.rs:644-646
+    c->state = false;                                                                          // ram.rs:648
     return FHERAM_OK;
 }
 
@@ -391,8 +475,14 @@ int fheram_params_default(fheram_params* p) {
 const char* fheram_last_error(const fheram_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 int fheram_ctx_create(const fheram_params* p, int device, fheram_ctx** out) {
+    return fheram_ctx_create_sharded(p, device, 0, 1, out);
+}
+
+int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int n_shards, fheram_ctx** out) {
     if (!p || !out) return fail(nullptr, FHERAM_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
+    if (n_shards < 1 || shard < 0 || shard >= n_shards || (n_shards & (n_shards - 1)) != 0)
+        return fail(nullptr, FHERAM_ERR_INVALID_ARG, "n_shards must be a power of two and 0 <= shard < n_shards");
     // The kernels are built for the reference's cryptographic parameters (parameters.rs:11-18).
     if (p->log_n != 12 || p->base2k != 17 || p->rank != 1 || p->k_glwe_ct != 51 || p->k_ggsw_addr != 68 ||
         p->k_evk_trace != 68 || p->k_evk_ggsw_inv != 85)
@@ -411,7 +501,13 @@ int fheram_ctx_create(const fheram_params* p, int device, fheram_ctx** out) {
 
     fheram_ctx* c = new fheram_ctx();
     c->p = *p; c->device = device; c->ws = (int)p->word_size;
-    c->rows = (size_t)((p->max_addr + N - 1) / N);
+    c->rows_glob = (size_t)((p->max_addr + N - 1) / N);
+    c->shard = shard; c->n_shards = n_shards;
+    if (n_shards > 1 && ((c->rows_glob & (c->rows_glob - 1)) != 0 || c->rows_glob < (size_t)n_shards)) {
+        delete c;
+        return fail(nullptr, FHERAM_ERR_INVALID_ARG, "row sharding needs a power-of-two number of rows >= n_shards (else: replicas only)");
+    }
+    c->rows = c->rows_glob / (size_t)n_shards;
     {   // get_base_2d (base.rs:84-108)
         uint32_t x = (uint32_t)(p->max_addr - 1), bits = 0;
         while (x) { bits++; x >>= 1; }
@@ -476,6 +572,8 @@ int fheram_ctx_create(const fheram_params* p, int device, fheram_ctx** out) {
     CCHK(hipMalloc(&c->d_scrB, nrow * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_scrC, nrow * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tmp2, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_part, (size_t)c->ws * G * sizeof(int32_t)));
+    if (n_shards > 1) for (int i = 0; i < 3; i++) CCHK(hipMalloc(&c->d_gat[i], (size_t)n_shards * c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tree, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_res, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tmp, (size_t)c->ws * G * sizeof(int32_t)));
@@ -496,7 +594,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_scrC, c->d_tmp2, c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_scrC, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -607,6 +705,7 @@ int fheram_sync(fheram_ctx* c) {
 int fheram_read(fheram_ctx* c, const fheram_addr* addr, int64_t* out) {
     int rc = check_common(c, addr);
     if (rc != FHERAM_OK) return rc;
+    if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_read_partial / fheram_read_finish");
     if (c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
     HIPCHK(c, hipSetDevice(c->device));
     rc = read_impl(c, addr, false);
@@ -617,6 +716,7 @@ int fheram_read(fheram_ctx* c, const fheram_addr* addr, int64_t* out) {
 int fheram_read_prepare_write(fheram_ctx* c, const fheram_addr* addr, int64_t* out) {
     int rc = check_common(c, addr);
     if (rc != FHERAM_OK) return rc;
+    if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_read_partial / fheram_read_finish");
     if (c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
     HIPCHK(c, hipSetDevice(c->device));
     rc = read_impl(c, addr, true);
@@ -641,38 +741,96 @@ int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* ad
     HIPCHK(c, hipSetDevice(c->device));
     if (w) { rc = fheram_word_stage(c, w, n_w); if (rc != FHERAM_OK) return rc; }
     else if (!c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
-    const long G = (long)fheram_ctx::GLWE;
-    const long sy = (long)c->rows * G;
-    const int ws = c->ws, R = (int)c->rows;
-    GlweRef wref = ref(c->d_w, G, 0), tmp = ref(c->d_tmp, G, 0), tmp2 = ref(c->d_tmp2, G, 0), tree = ref(c->d_tree, G, 0);
-    GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G), C = ref(c->d_scrC, sy, G);
-    // write_first_step (ram.rs:544-577): t <- normalize(t - trace(t) + w)
-    GlweRef top = (c->n2 != 1) ? tree : ref(c->d_data, sy, 0);
-    trace_steps(c, top, tmp, tmp2, 0, LOGN, 1, ws);
-    {
-        ProfScope ps(c, "elementwise", ws);
-        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws), dim3(256), 0, c->stream, top, tmp, wref, top);
-    }
-    if (c->n2 == 2) {
-        // mid step for i = 0 (ram.rs:258-276, 579-632)
-        coordinate_prepare_inv(c, addr, 1);
-        ep_chain(c, tree, tree, tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);   // ram.rs:610
-        trace_steps(c, data, A, C, 0, LOGN, R, ws);                                  // tmp_a = trace(ct_hi)            ram.rs:616
-        trace_steps(c, tree, B, C, 0, LOGN, R, ws, 1);                               // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
-        {
-            ProfScope ps(c, "elementwise", (uint64_t)R * ws);
-            hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws), dim3(256), 0, c->stream, data, A, B, data);   // ram.rs:617,625-626
-        }
-        {   // ct_lo has been rotated `rows` times by X^-1 (ram.rs:629)
-            ProfScope ps(c, "elementwise", ws);
-            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws), dim3(256), 0, c->stream, tree, tmp, -R);
-        }
-        launch_copy(c, tmp, tree, 1, ws);
-    }
-    // last step (ram.rs:278-293, 634-649)
-    coordinate_prepare_inv(c, addr, 0);
-    ep_chain(c, data, data, A, c->d_prep, (int)c->base2d[0].size(), R, ws);
+    if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_write_root / fheram_write_shard");
+    rc = write_top(c, addr);
+    if (rc == FHERAM_OK) rc = write_rows(c, addr);
+    if (rc != FHERAM_OK) return rc;
     c->state = false;
+    HIPCHK(c, hipGetLastError());
+    return FHERAM_OK;
+}
+
+// ---- row-sharded RAM ------------------------------------------------------------
+namespace {
+// copies ws GLWEs between the context and a caller buffer: device int32 [ws][GLWE] or host int64
+int export_glwes(fheram_ctx* c, const int32_t* src, void* dst, int on_device, size_t n_glwe) {
+    const size_t n = n_glwe * fheram_ctx::GLWE;
+    if (on_device) { HIPCHK(c, hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, c->stream)); return FHERAM_OK; }
+    return download_i64(c, (int64_t*)dst, src, n);
+}
+int import_glwes(fheram_ctx* c, int32_t* dst, const void* src, int on_device, size_t n_glwe) {
+    const size_t n = n_glwe * fheram_ctx::GLWE;
+    if (on_device) { HIPCHK(c, hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, c->stream)); return FHERAM_OK; }
+    return upload_i64(c, dst, (const int64_t*)src, n);
+}
+}  // namespace
+
+int fheram_shard_info(const fheram_ctx* c, int* shard, int* n_shards, size_t* local_rows) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    if (shard) *shard = c->shard;
+    if (n_shards) *n_shards = c->n_shards;
+    if (local_rows) *local_rows = c->rows;
+    return FHERAM_OK;
+}
+int fheram_read_partial(fheram_ctx* c, const fheram_addr* addr, int prepare_write, void* out, int out_on_device) {
+    int rc = check_common(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    if (!out) return fail(c, FHERAM_ERR_INVALID_ARG, "null output");
+    if (c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = read_local(c, addr, prepare_write != 0);
+    if (rc != FHERAM_OK) return rc;
+    HIPCHK(c, hipGetLastError());
+    if (prepare_write) c->state = true;
+    rc = export_glwes(c, c->d_part, out, out_on_device, (size_t)c->ws);
+    if (rc == FHERAM_OK && out_on_device) HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller's collective runs on another stream
+    return rc;
+}
+int fheram_read_finish(fheram_ctx* c, const fheram_addr* addr, int prepare_write, const void* partials, int partials_on_device, int64_t* out) {
+    int rc = check_common(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    if (!partials) return fail(c, FHERAM_ERR_INVALID_ARG, "null partials");
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t* gathered = nullptr;
+    if (c->n_shards > 1) {
+        rc = import_glwes(c, c->d_gat[0], partials, partials_on_device, (size_t)c->n_shards * c->ws);
+        gathered = c->d_gat[0];
+    } else {
+        rc = import_glwes(c, c->d_part, partials, partials_on_device, (size_t)c->ws);
+    }
+    if (rc != FHERAM_OK) return rc;
+    rc = read_top(c, addr, prepare_write != 0, gathered);
+    if (rc != FHERAM_OK) return rc;
+    HIPCHK(c, hipGetLastError());
+    return out ? fheram_result_download(c, out) : fheram_sync(c);
+}
+int fheram_write_root(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* addr, void* ct_lo_out, int out_on_device) {
+    int rc = check_common(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    if (n_w != c->ws) return fail(c, FHERAM_ERR_INVALID_ARG, "w.len() != subrams.len() (ram.rs:243)");
+    if (c->n2 != 2) return fail(c, FHERAM_ERR_INVALID_ARG, "a row-sharded RAM has two coordinates");
+    if (!c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
+    if (!ct_lo_out) return fail(c, FHERAM_ERR_INVALID_ARG, "null output");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (w) { rc = fheram_word_stage(c, w, n_w); if (rc != FHERAM_OK) return rc; }
+    else if (!c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
+    rc = write_top(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    HIPCHK(c, hipGetLastError());
+    rc = export_glwes(c, c->d_part, ct_lo_out, out_on_device, (size_t)c->ws);
+    if (rc == FHERAM_OK && out_on_device) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return rc;
+}
+int fheram_write_shard(fheram_ctx* c, const fheram_addr* addr, const void* ct_lo, int on_device) {
+    int rc = check_common(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    if (!ct_lo) return fail(c, FHERAM_ERR_INVALID_ARG, "null ct_lo");
+    if (!c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = import_glwes(c, c->d_part, ct_lo, on_device, (size_t)c->ws);
+    if (rc != FHERAM_OK) return rc;
+    rc = write_rows(c, addr);
+    if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
     return FHERAM_OK;
 }
@@ -748,7 +906,8 @@ int fheram_glwe_pack(fheram_ctx* c, const int64_t* cts, int count, int64_t* out)
     HIPCHK(c, hipMalloc(&B.p, (size_t)count * G * 4));
     int rc = upload_i64(c, src.p, cts, (size_t)count * G);
     if (rc != FHERAM_OK) return rc;
-    int32_t* packed = pack_levels(c, src.p, A.p, B.p, 0, (long)G, (size_t)count, 1);
+    const int L0p = LOGN - ilog2_ceil((size_t)count);
+    int32_t* packed = pack_levels(c, src.p, A.p, B.p, 0, (long)G, (size_t)count, 1, L0p, L0p);
     HIPCHK(c, hipGetLastError());
     return download_i64(c, out, packed, G);
 }

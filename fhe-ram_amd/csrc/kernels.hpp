@@ -243,7 +243,8 @@ struct KsArgs {
     int g;               // Galois element mod 2N (odd, in [1, 2N))
     int ginv;            // g^-1 mod 2N
     int t;               // KS_PAIR: rotation amount (N >> (level+1))
-    int rot_mul;         // KS_TRACE: rho = -(blockIdx.x * rot_mul)   (write path: ct_lo * X^-row)
+    int rot_mul;         // KS_TRACE: rho = -(rot_base + blockIdx.x * rot_mul)   (write path: ct_lo * X^-row;
+    int rot_base;        //           row = shard + x * n_shards when the RAM is sharded by rows)
 };
 
 // sign * a[(limb, col)][src] for the coefficient at position i of rot(a, rho)
@@ -259,7 +260,7 @@ template <int MODE, int SX>
 __device__ __forceinline__ void load_x(const KsArgs& ka, const int32_t* ap, const int32_t* bp, int col, int i, int (&x)[SX]) {
     if constexpr (MODE == KS_TRACE) {
         int src; bool sgn;
-        rot_src(i, -(int)blockIdx.x * ka.rot_mul, src, sgn);
+        rot_src(i, -(ka.rot_base + (int)blockIdx.x * ka.rot_mul), src, sgn);
         int v[SX];
 #pragma unroll
         for (int j = 0; j < SX; j++) v[j] = cneg(ap[glwe_off(j, col) + src], sgn);

@@ -110,6 +110,29 @@ int fheram_result_download(fheram_ctx* ctx, int64_t* out);
 /* Block until every queued operation of ctx has finished. */
 int fheram_sync(fheram_ctx* ctx);
 
+/* ---- Row-sharded RAM across the GPUs of a node.  The reference is single
+ * threaded and has no counterpart; the split follows its control flow: the rows of one residue class
+ * mod n_shards form a complete sub-tree of the GLWEPacker (bit-reversed feed, ram.rs:425-444), so a
+ * shard that owns rows r = shard (mod n_shards) of every sub-RAM runs SubRam::read up to and
+ * including its own packing levels; one exchange (all-gather of word_size GLWEs per shard) later the
+ * root finishes the top log2(n_shards) levels, the coordinate-1 products and the trace.  Every
+ * combine sees the same operands as in the sequential packer, so results are bit-identical.
+ * Buffers are either host int64 ([..][GLWE], *_on_device = 0) or device int32 in the same
+ * [limb][col][N] order (*_on_device = 1; the pointer must be valid on the context's device —
+ * this is what an RCCL collective moves). */
+int fheram_ctx_create_sharded(const fheram_params* params, int device, int shard, int n_shards, fheram_ctx** out);
+int fheram_shard_info(const fheram_ctx* ctx, int* shard, int* n_shards, size_t* local_rows);
+/* Every shard.  out: word_size partial GLWEs.  prepare_write != 0 keeps the rotated rows (ram.rs:502-504). */
+int fheram_read_partial(fheram_ctx* ctx, const fheram_addr* addr, int prepare_write, void* out, int out_on_device);
+/* Root.  partials: [n_shards][word_size] GLWEs in shard order.  out as in fheram_read (may be NULL). */
+int fheram_read_finish(fheram_ctx* ctx, const fheram_addr* addr, int prepare_write, const void* partials,
+                       int partials_on_device, int64_t* out);
+/* Root: write_first_step + inverse coordinate-1 products (ram.rs:254-256,260-271,610).  ct_lo_out:
+ * word_size GLWEs to broadcast. */
+int fheram_write_root(fheram_ctx* ctx, const int64_t* w, int n_w, const fheram_addr* addr, void* ct_lo_out, int out_on_device);
+/* Every shard: write_mid_step on its rows with the broadcast ct_lo, then write_last_step (ram.rs:612-630,644-648). */
+int fheram_write_shard(fheram_ctx* ctx, const fheram_addr* addr, const void* ct_lo, int on_device);
+
 /* ---- Poulpy-level operations reached from the path, exposed for
  * parity tests and micro-benchmarks.  Inputs/outputs are host buffers in the layouts above. */
 

@@ -193,6 +193,19 @@ int fo_glwe_pack(void* c, void* keys, const int64_t* cts, const uint8_t* present
     packer_flush(*x, pk, out);
     FO_CATCH
 }
+// One GLWEPacker combine at level i on an accumulator that holds a value (acc.value == true):
+// a <- combine(a, b) with b == NULL meaning "no ciphertext" (SURVEY.md A.7).  Used by the tests to
+// replay the packer level by level (row-sharded schedule).
+int fo_packer_combine(void* c, void* keys, int64_t* a, const int64_t* b, int i) {
+    FO_TRY
+    Ctx* x = (Ctx*)c; KeysHandle* k = (KeysHandle*)keys;
+    Packer pk; pk.n = x->n(); pk.size = x->p.size_ct();
+    Accumulator acc; acc.value = true; acc.control = true;
+    acc.data.assign(a, a + x->p.glwe_len(pk.size));
+    packer_combine(*x, pk, acc, b, i, k->k.atk_glwe);
+    std::memcpy(a, acc.data.data(), sizeof(int64_t) * acc.data.size());
+    FO_CATCH
+}
 int fo_ggsw_automorphism_inv(void* c, void* keys, const int64_t* in, int64_t* out) {
     FO_TRY
     Ctx* x = (Ctx*)c; KeysHandle* k = (KeysHandle*)keys;

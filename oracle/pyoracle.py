@@ -83,6 +83,7 @@ def lib():
         L.fo_glwe_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, I64P]
         L.fo_glwe_pack.argtypes = [C.c_void_p, C.c_void_p, I64P, U8P, I64P]
         L.fo_ggsw_automorphism_inv.argtypes = [C.c_void_p, C.c_void_p, I64P, I64P]
+        L.fo_packer_combine.argtypes = [C.c_void_p, C.c_void_p, I64P, I64P, C.c_int]
         L.fo_ram_new.restype = C.c_void_p
         L.fo_ram_new.argtypes = [C.c_void_p]
         L.fo_ram_free.argtypes = [C.c_void_p]
@@ -391,6 +392,13 @@ class Oracle:
         out = np.zeros(self.p.glwe_len, dtype=np.int64)
         _chk(lib().fo_glwe_pack(self.h, keys.h, _p(cts), _u8(present), _p(out)))
         return out
+
+    def packer_combine(self, keys, a, b, level):
+        """a <- GLWEPacker combine(a, b) at `level`; b may be None."""
+        a = np.array(a, dtype=np.int64).ravel().copy()
+        bp = None if b is None else _p(np.ascontiguousarray(b, dtype=np.int64).ravel())
+        _chk(lib().fo_packer_combine(self.h, keys.h, _p(a), bp, level))
+        return a
 
     def ggsw_automorphism_inv(self, keys, ggsw):
         out = np.zeros(self.p.ggsw_len, dtype=np.int64)
