@@ -69,6 +69,19 @@ def algorithmic_bytes(max_addr, ws, n_digits):
     return read, rpw, write
 
 
+def pmc_traffic_per_launch(kernel_prefix):
+    """HBM bytes per launch of a kernel class from the committed PMC profile (None if absent)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tot, n = 0.0, 0
+    for k, v in json.load(open(path)).items():
+        if kernel_prefix in k and "FETCH_SIZE_per_launch" in v and "WRITE_SIZE_per_launch" in v:
+            tot += v["launches"] * (2.0 * v["FETCH_SIZE_per_launch"] + v["WRITE_SIZE_per_launch"]) * 1024.0
+            n += v["launches"]
+    return tot / n if n else None
+
+
 def cpu_baseline(max_addr, seed):
     """Times the oracle (CPU restatement, kind 'port') on a bounded sample of the same workload:
     ONE of the WORDSIZE sub-RAMs of the 2^18 RAM (sub-RAMs are processed one after the other by
@@ -103,6 +116,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-max-addr", type=int, default=18)
     ap.add_argument("--word-size", type=int, default=4)
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="N > 1: 'replicas' = one independent 2^log_max_addr RAM per GPU (default, weak scaling in RAM "
+                         "ops/s); 'sharded' = ONE RAM of N * 2^log_max_addr entries, rows sharded over the GPUs "
+                         "(BASELINE.json configs[4]); one RCCL all-gather per read, one broadcast per write")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
+    ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
@@ -117,27 +136,40 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.all_ranks_device0:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)   # nccl == RCCL on ROCm
 
     from _pkg import load_package
     pkg = load_package()
     max_addr, ws = 1 << args.log_max_addr, args.word_size
-    ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr, device=local_rank)
+    sharded = args.mode == "sharded" and world > 1
+    if sharded:
+        max_addr *= world                      # weak scaling of ONE RAM: 2^log_max_addr entries per GPU
+        ram = pkg.Ram(pkg.Parameters(max_addr=max_addr, word_size=ws), device=local_rank, shard=rank, n_shards=world)
+    else:
+        ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr, device=local_rank)
     p = ram.params
     rng = np.random.default_rng(1234 + rank)
     n_digits = p.base2d().as_1d().size()
     keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(synth(rng, (12, 3 * 4 * 2 * N))),
                                       synth(rng, 4 * 5 * 2 * N), synth(rng, 4 * 5 * 2 * N))
     addr = pkg.Address(p, list(synth(rng, (n_digits, p.ggsw_len()))))
-    ram.load_encrypted(synth(rng, (ws, p.rows(), p.glwe_len())))
+    ram.load_encrypted(synth(rng, (ws, ram.local_rows(), p.glwe_len())))
     ram.stage_words(synth(rng, (ws, p.glwe_len())))
+    if sharded:
+        from fheram_amd.sharded import ShardedRam, TorchComm
+        sram = ShardedRam(ram, TorchComm(device_buffers=args.dist_backend == "nccl"), download=False)
+        ops = (lambda: sram.read(addr, keys), lambda: sram.read_prepare_write(addr, keys), lambda: sram.write(None, addr, keys))
+    else:
+        ops = (lambda: ram.read(addr, keys, download=False),
+               lambda: ram.read_prepare_write(addr, keys, download=False),
+               lambda: ram.write(None, addr, keys))
 
     def step(timed):
         ts = []
-        for fn in (lambda: ram.read(addr, keys, download=False),
-                   lambda: ram.read_prepare_write(addr, keys, download=False),
-                   lambda: ram.write(None, addr, keys)):
+        for fn in ops:
             ram.timer_begin()
             fn()
             ts.append(ram.timer_end())
@@ -163,7 +195,7 @@ def main():
     ram.profile_enable(False)
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -175,7 +207,8 @@ def main():
     per_op = np.array(per_op)              # [steps][3] ms, HIP events on the context's stream
     read_ms, rpw_ms, write_ms = per_op.mean(axis=0)
     ms_per_step = elapsed * 1e3 / args.steps
-    ops_per_s = world * 2 * args.steps / elapsed
+    n_rams = 1 if sharded else world
+    ops_per_s = n_rams * 2 * args.steps / elapsed
     a_read, a_rpw, a_write = algorithmic_bytes(max_addr, ws, n_digits)
     cnt = op_counts(max_addr, ws, p.base2d())
 
@@ -183,12 +216,14 @@ def main():
         "metric": f"encrypted RAM read ops/s + write ops/s at 2^{args.log_max_addr} entries; achieved HBM GB/s vs peak",
         "value": ops_per_s, "unit": "RAM ops/s (1 read + 1 write[=rpw+write] per step)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (exact integers mod 2^48+57345)",
+        "higher_is_better": True, "scaling": "weak", "mode": args.mode, "vs_baseline": None, "dtype": "f64 (exact integers mod 2^48+57345)",
         "data": "synthetic",
         "config": {"workload": f"Ram::read + Ram::read_prepare_write + Ram::write, MAX_ADDR=2^{args.log_max_addr}, "
                                f"WORDSIZE={ws}, N=4096, base2k=17, rank=1 (BASELINE.json configs[2]+[3])",
-                   "rams": world, "rows_per_subram": cnt["rows"], "parallelism": f"{world} independent RAM(s), one per GPU"},
-        "read_ops_s": world * 1e3 / read_ms, "write_ops_s": world * 1e3 / (rpw_ms + write_ms),
+                   "rams": n_rams, "rows_per_subram": cnt["rows"],
+                   "parallelism": (f"1 RAM of 2^{args.log_max_addr}*{world} entries, rows sharded over {world} GPUs (RCCL all-gather/broadcast)"
+                                   if sharded else f"{world} independent RAM(s), one per GPU")},
+        "read_ops_s": n_rams * 1e3 / read_ms, "write_ops_s": n_rams * 1e3 / (rpw_ms + write_ms),
         "read_ms": read_ms, "read_prepare_write_ms": rpw_ms, "write_ms": write_ms,
         "algorithmic_GBs_per_op": {"read": a_read / read_ms / 1e6, "read_prepare_write": a_rpw / rpw_ms / 1e6,
                                    "write": a_write / write_ms / 1e6},
@@ -211,7 +246,9 @@ def main():
             achieved = bytes_per_launch / avg_ms / 1e6
             out["roofline"] = {"kernel": "k_keyswitch (glwe_automorphism family: trace step / packer combine)",
                                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch("k_keyswitch"),
+                               "traffic_source": "profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                 "passes of this command; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, launch-weighted mean)",
                                "avg_launch_ms": avg_ms, "avg_blocks_per_launch": blocks, "launches": ks["launches"],
                                "algorithmic_bytes_per_launch": bytes_per_launch}
             # companion VALU roofline: 11 transforms x 24576 butterflies x 8 FP64 ops + 24 x 4096 MACs x 7

@@ -85,8 +85,9 @@ class ShardedRam:
     engine: object with read_partial / read_finish / write_root / write_shard (fheram_amd.Ram created
             with shard/n_shards) and .params."""
 
-    def __init__(self, engine, comm: TorchComm, root: int = 0):
-        self.engine, self.comm, self.root = engine, comm, root
+    def __init__(self, engine, comm: TorchComm, root: int = 0, download: bool = True):
+        """download=False leaves the result of a read on the root's device (engine.result() fetches it)."""
+        self.engine, self.comm, self.root, self.download = engine, comm, root, download
         p = engine.params
         self.ws, self.glen = p.word_size(), p.glwe_len()
         self._part = comm.alloc(self.ws, self.glen)
@@ -97,7 +98,7 @@ class ShardedRam:
         self.engine.read_partial(address, keys, prepare_write, out=c.handle(self._part))
         gathered = c.all_gather(self._part, self.ws, self.glen)          # the one exchange step of a read
         if c.rank == self.root:
-            return self.engine.read_finish(address, keys, c.handle(gathered), prepare_write)
+            return self.engine.read_finish(address, keys, c.handle(gathered), prepare_write, download=self.download)
         return None
 
     def read(self, address, keys):

@@ -81,3 +81,20 @@ def test_product_package_never_imports_the_oracle():
                 assert "pyoracle" not in txt and "liboracle" not in txt, f
                 assert not re.search(r"#include\s*[<\"][^>\"]*oracle", txt), f
                 assert not re.search(r"^\s*(from|import)\s+\S*oracle", txt, flags=re.M), f
+
+
+def test_cpp_host_mirror_builds_and_links(tmp_path):
+    """fhe-ram_amd/host/fheram.hpp (the C++ mirror of the reference API) compiles against the C ABI
+    and, on a box without a GPU, fails loudly with the C ABI's DEVICE status."""
+    import shutil
+    import subprocess
+    pkg = load_package()
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    host = os.path.join(ROOT, "fhe-ram_amd", "host")
+    exe = str(tmp_path / "host_check")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-o", exe, os.path.join(host, "host_check.cpp"),
+                           "-L" + os.path.dirname(pkg.library_path()), "-lfheram",
+                           "-Wl,-rpath," + os.path.dirname(pkg.library_path())])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
