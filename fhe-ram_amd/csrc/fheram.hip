@@ -55,7 +55,10 @@ struct ProfCls {
 struct fheram_ctx {
     fheram_params p;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // main stream: every op is ordered on it
+    hipStream_t stream2 = nullptr;   // side stream for work that is independent inside one op (write path)
+    hipStream_t cur = nullptr;       // stream the launchers currently enqueue on
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // derived
     int ws = 0, n2 = 0, n_digits = 0;
     size_t rows = 0;        // GLWE rows per sub-RAM held by THIS context (all of them unless sharded)
@@ -81,6 +84,7 @@ struct fheram_ctx {
     int32_t* d_scrA = nullptr;     // [ws][rows]  ping-pong arenas: every fused kernel is out of place
     int32_t* d_scrB = nullptr;     // [ws][rows]
     int32_t* d_scrC = nullptr;     // [ws][rows]
+    int32_t* d_scrD = nullptr;     // [ws][rows]
     int32_t* d_res = nullptr;      // [ws]
     int32_t* d_tmp = nullptr;      // [ws]
     int32_t* d_tmp2 = nullptr;     // [ws]
@@ -91,7 +95,9 @@ struct fheram_ctx {
                                    // ciphertext), 2 = one workgroup, 0 = choose per launch from the batch size
     int cus = 256;
     double* d_prep = nullptr;      // [max digits per coordinate] prepared GGSW
+    double* d_prep2 = nullptr;     // second set (inverse coordinate 0, prepared on the side stream)
     int32_t* d_ggsw_tmp = nullptr; // [max digits per coordinate] std GGSW (inversion result)
+    int32_t* d_ggsw_tmp2 = nullptr;
     int max_digits = 0;
     bool initialized = false, state = false, words_staged = false;
     std::vector<int32_t> h_i32;    // host staging
@@ -136,12 +142,12 @@ struct ProfScope {
         cls = &c->prof[name];
         cls->launches++; cls->blocks += blocks;
         a = get_event(c);
-        hipEventRecord(a, c->stream);
+        hipEventRecord(a, c->cur);
     }
     ~ProfScope() {
         if (!cls) return;
         hipEvent_t b = get_event(c);
-        hipEventRecord(b, c->stream);
+        hipEventRecord(b, c->cur);
         cls->pending.emplace_back(a, b);
     }
 };
@@ -200,6 +206,7 @@ int download_i64(fheram_ctx* c, int64_t* dst, const int32_t* src, size_t n) {
 }
 
 // ---- kernel launchers ---------------------------------------------------------------------
+constexpr int EW_SLICES = 8;   // workgroups per ciphertext of the elementwise kernels (blockIdx.z)
 // One workgroup per ciphertext does the least work (no repeated forward transforms); splitting by
 // output column doubles the number of workgroups, which pays while the batch cannot fill the CUs.
 int pick_nco(const fheram_ctx* c, int gx, int gy) {
@@ -208,26 +215,26 @@ int pick_nco(const fheram_ctx* c, int gx, int gy) {
 }
 void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly) {
     ProfScope ps(c, "prepare", npoly);
-    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->stream, in, out, c->d_tw, c->ninv);
+    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->cur, in, out, c->d_tw, c->ninv);
 }
 // res = a (x) ggsw over a (gx, gy) grid of ciphertexts; res must not alias a
 void launch_ep(fheram_ctx* c, GlweRef a, GlweRef res, const double* ggsw, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "ext_product", (uint64_t)gx * gy);
-    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_ext_product<3, 4, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->stream, a, res, ggsw, c->d_tw);
-    else hipLaunchKernelGGL((k_ext_product<3, 4, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->stream, a, res, ggsw, c->d_tw);
+    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_ext_product<3, 4, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw);
+    else hipLaunchKernelGGL((k_ext_product<3, 4, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw);
 }
 template <int MODE, int SX, int SK, int SO>
 void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "keyswitch", (uint64_t)gx * gy);
-    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->stream, ka);
-    else hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->stream, ka);
+    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);
+    else hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ka);
 }
 void launch_copy(fheram_ctx* c, GlweRef src, GlweRef dst, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "elementwise", (uint64_t)gx * gy);
-    hipLaunchKernelGGL((k_copy<3>), dim3(gx, gy), dim3(256), 0, c->stream, src, dst);
+    hipLaunchKernelGGL((k_copy<3>), dim3(gx, gy, EW_SLICES), dim3(256), 0, c->cur, src, dst);
 }
 KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* key, int64_t gal, int t = 0, int rot_mul = 0, int rot_base = 0) {
     KsArgs ka;
@@ -323,10 +330,10 @@ void ggsw_inverse(fheram_ctx* c, const int32_t* in, int32_t* tmp, int d) {
     KsArgs kt = ks_args(c, ref(tmp, (long)fheram_ctx::GGSW, 2 * g4), ref(tmp, 0, 0), ref(tmp + g4, (long)fheram_ctx::GGSW, 2 * g4), c->d_tsk, 1);
     launch_ks<KS_TENSOR, 4, 5, 4>(c, kt, fheram_ctx::DNUM_CT, d);
 }
-void coordinate_prepare_inv(fheram_ctx* c, const fheram_addr* addr, int ci) {
+void coordinate_prepare_inv(fheram_ctx* c, const fheram_addr* addr, int ci, int32_t* tmp, double* prep) {
     const int d = (int)c->base2d[ci].size();
-    ggsw_inverse(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, c->d_ggsw_tmp, d);
-    launch_prepare(c, c->d_ggsw_tmp, c->d_prep, d * (int)(fheram_ctx::GGSW / N));
+    ggsw_inverse(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, tmp, d);
+    launch_prepare(c, tmp, prep, d * (int)(fheram_ctx::GGSW / N));
 }
 
 int check_common(fheram_ctx* c, const fheram_addr* addr) {
@@ -425,34 +432,49 @@ int write_top(fheram_ctx* c, const fheram_addr* addr) {
     trace_steps(c, top, tmp, tmp2, 0, LOGN, 1, ws);
     {
         ProfScope ps(c, "elementwise", ws);
-        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws), dim3(256), 0, c->stream, top, tmp, wref, top);
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, top, tmp, wref, top);
     }
     if (c->n2 == 2) {
-        coordinate_prepare_inv(c, addr, 1);                                           // ram.rs:260-271
+        coordinate_prepare_inv(c, addr, 1, c->d_ggsw_tmp, c->d_prep);                 // ram.rs:260-271
         ep_chain(c, tree, tree, tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);     // ram.rs:610
         launch_copy(c, tree, ref(c->d_part, G, 0), 1, ws);
         {   // ct_lo ends up rotated `rows` times by X^-1 (ram.rs:629)
             ProfScope ps(c, "elementwise", ws);
-            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws), dim3(256), 0, c->stream, tree, tmp, -(int)c->rows_glob);
+            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, tree, tmp, -(int)c->rows_glob);
         }
         launch_copy(c, tmp, tree, 1, ws);
     }
     return FHERAM_OK;
+}
+// Work of a write that does not depend on stage 1: tmp_a = trace(ct_hi) for every local row
+// (ram.rs:616) and the inverse of coordinate 0 (ram.rs:278-289).  It is enqueued on the side stream
+// so that it fills the CUs the latency-bound stage 1 (a chain of word_size-ciphertext launches)
+// leaves idle.
+void write_side_begin(fheram_ctx* c, const fheram_addr* addr) {
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    hipEventRecord(c->ev_fork, c->stream);            // everything before this write (rows after rpw)
+    hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+    c->cur = c->stream2;
+    if (c->n2 == 2) trace_steps(c, ref(c->d_data, sy, G), ref(c->d_scrA, sy, G), ref(c->d_scrC, sy, G), 0, LOGN, (int)c->rows, c->ws);
+    coordinate_prepare_inv(c, addr, 0, c->d_ggsw_tmp2, c->d_prep2);
+    hipEventRecord(c->ev_join, c->stream2);
+    c->cur = c->stream;
 }
 // Stage 2 (every shard): write_mid_step on the local rows given ct_lo (in d_part), then write_last_step.
 int write_rows(fheram_ctx* c, const fheram_addr* addr) {
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     const int ws = c->ws, R = (int)c->rows;
-    GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G), C = ref(c->d_scrC, sy, G);
+    GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G), D = ref(c->d_scrD, sy, G);
+    if (c->n2 == 2)
+        trace_steps(c, ref(c->d_part, G, 0), B, D, 0, LOGN, R, ws, c->n_shards, c->shard);     // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
+    hipStreamWaitEvent(c->stream, c->ev_join, 0);                                              // side stream: trace(ct_hi), inverse coordinate 0
     if (c->n2 == 2) {
-        trace_steps(c, data, A, C, 0, LOGN, R, ws);                                            // tmp_a = trace(ct_hi)            ram.rs:616
-        trace_steps(c, ref(c->d_part, G, 0), B, C, 0, LOGN, R, ws, c->n_shards, c->shard);     // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
         ProfScope ps(c, "elementwise", (uint64_t)R * ws);
-        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws), dim3(256), 0, c->stream, data, A, B, data);   // ram.rs:617,625-626
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws, EW_SLICES), dim3(256), 0, c->cur, data, A, B, data);   // ram.rs:617,625-626
     }
-    coordinate_prepare_inv(c, addr, 0);                                                        // ram.rs:278-289
-    ep_chain(c, data, data, A, c->d_prep, (int)c->base2d[0].size(), R, ws);                    // ram.rs:644-646
+    ep_chain(c, data, data, A, c->d_prep2, (int)c->base2d[0].size(), R, ws);                   // ram.rs:644-646
     c->state = false;                                                                          // ram.rs:648
     return FHERAM_OK;
 }
@@ -536,6 +558,10 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     } while (0)
     CCHK(hipSetDevice(device));
     CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    c->cur = c->stream;
+    CCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     CCHK(hipEventCreate(&c->t0));
     CCHK(hipEventCreate(&c->t1));
     {
@@ -571,6 +597,9 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_scrA, nrow * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_scrB, nrow * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_scrC, nrow * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_scrD, nrow * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_prep2, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(double)));
+    CCHK(hipMalloc(&c->d_ggsw_tmp2, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tmp2, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_part, (size_t)c->ws * G * sizeof(int32_t)));
     if (n_shards > 1) for (int i = 0; i < 3; i++) CCHK(hipMalloc(&c->d_gat[i], (size_t)n_shards * c->ws * G * sizeof(int32_t)));
@@ -590,11 +619,15 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream2) hipStreamSynchronize(c->stream2);
     prof_collect(c);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_scrC, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -742,6 +775,7 @@ int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* ad
     if (w) { rc = fheram_word_stage(c, w, n_w); if (rc != FHERAM_OK) return rc; }
     else if (!c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
     if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_write_root / fheram_write_shard");
+    write_side_begin(c, addr);
     rc = write_top(c, addr);
     if (rc == FHERAM_OK) rc = write_rows(c, addr);
     if (rc != FHERAM_OK) return rc;
@@ -827,6 +861,7 @@ int fheram_write_shard(fheram_ctx* c, const fheram_addr* addr, const void* ct_lo
     if (!ct_lo) return fail(c, FHERAM_ERR_INVALID_ARG, "null ct_lo");
     if (!c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
     HIPCHK(c, hipSetDevice(c->device));
+    write_side_begin(c, addr);   // (a shard could start this before the broadcast arrives; kept here for a simple contract)
     rc = import_glwes(c, c->d_part, ct_lo, on_device, (size_t)c->ws);
     if (rc != FHERAM_OK) return rc;
     rc = write_rows(c, addr);

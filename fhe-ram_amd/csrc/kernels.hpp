@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void k_sub_add_norm(GlweRef a, GlweRef b, Glwe
     const int32_t* bp = at(b);
     const int32_t* cp = at(c);
     int32_t* op = at(out);
-    for (int idx = threadIdx.x; idx < 2 * N; idx += blockDim.x) {
+    for (int idx = blockIdx.z * blockDim.x + threadIdx.x; idx < 2 * N; idx += blockDim.x * gridDim.z) {
         const int col = idx >> LOGN, i = idx & (N - 1);
         double in_l[S], out_l[S];
 #pragma unroll
@@ -483,14 +483,14 @@ template <int S>
 __global__ __launch_bounds__(256) void k_copy(GlweRef a, GlweRef out) {
     const int4* ap = reinterpret_cast<const int4*>(at(a));
     int4* op = reinterpret_cast<int4*>(at(out));
-    for (int idx = threadIdx.x; idx < S * 2 * N / 4; idx += blockDim.x) op[idx] = ap[idx];
+    for (int idx = blockIdx.z * blockDim.x + threadIdx.x; idx < S * 2 * N / 4; idx += blockDim.x * gridDim.z) op[idx] = ap[idx];
 }
 // out = a * X^rho   (glwe_rotate, ram.rs:629); out must not alias a
 template <int S>
 __global__ __launch_bounds__(256) void k_rotate(GlweRef a, GlweRef out, int rho) {
     const int32_t* ap = at(a);
     int32_t* op = at(out);
-    for (int idx = threadIdx.x; idx < 2 * N; idx += blockDim.x) {
+    for (int idx = blockIdx.z * blockDim.x + threadIdx.x; idx < 2 * N; idx += blockDim.x * gridDim.z) {
         const int col = idx >> LOGN, i = idx & (N - 1);
         int src; bool sgn;
         rot_src(i, rho, src, sgn);
