@@ -997,6 +997,16 @@ int fheram_profile_get(fheram_ctx* c, const char* cls, uint64_t* launches, uint6
     return FHERAM_OK;
 }
 #ifdef FK_STAMP
+int fheram_debug_ntt_probe(fheram_ctx* c, int blocks) {
+    hipSetDevice(c->device);
+    double* sink = nullptr;
+    hipMalloc(&sink, (size_t)blocks * T * sizeof(double));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_ntt_probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_ntt_probe, dim3(blocks), dim3(T), LDS_BYTES, c->stream, c->d_tw, sink);
+    hipStreamSynchronize(c->stream);
+    hipFree(sink);
+    return 0;
+}
 // diagnostic build only: not part of include/fheram.h
 int fheram_debug_stamps(fheram_ctx* c, unsigned long long* out, int n) {
     hipSetDevice(c->device);

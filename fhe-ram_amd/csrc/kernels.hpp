@@ -400,21 +400,22 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             }
         };
 
-        // phi_g: destination i' takes +-source i, i = i' * ginv mod 2N (odd stride: conflict free)
+        // phi_g: destination i' takes +-source i, i = i' * ginv mod 2N (odd stride: conflict free).
+        // The write goes to this thread's own pattern-0 positions (no barrier needed before it); the
+        // gather reads other waves' data, so one barrier in between.
         auto permute = [&](auto& acc, auto nb) {
             constexpr int NB = decltype(nb)::value;
-            lds_barrier();
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
-                for (int k = 0; k < E; k++) data[b * LDS_DATA + tid + T * k] = acc[b][k];
+                for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<0>(tid + T * k)] = acc[b][k];
             lds_barrier();
             int sidx = (tid * ka.ginv) & (2 * N - 1);
             const int sstep = (T * ka.ginv) & (2 * N - 1);
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 const bool ng = sidx >= N;
-                const int s = sidx & (N - 1);
+                const int s = lay<0>(sidx & (N - 1));
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
                     const double d = data[b * LDS_DATA + s];
@@ -454,6 +455,66 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
         }
     }
 }
+
+#ifdef FK_STAMP
+// Diagnostic: one inverse + one forward transform with stamps between passes and exchanges.
+__global__ __launch_bounds__(T, T / 256) void k_ntt_probe(const double* __restrict__ tw_g, double* sink) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    double x[1][E];
+#pragma unroll
+    for (int k = 0; k < E; k++) x[0][k] = (double)(tid * 8 + k);
+    for (int rep = 0; rep < 2; rep++) {
+        STAMP(0);
+#pragma unroll
+        for (int k = 0; k < E; k++) x[0][k] = reduce(x[0][k]);
+        lds_barrier();
+        STAMP(1);
+        inv_pass<3>(x[0], tw, tid);
+        STAMP(2);
+        x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
+        exchange_inv<2, 1>(x, data, tid);
+        STAMP(3);
+        inv_pass<2>(x[0], tw, tid);
+        STAMP(4);
+        x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
+        exchange_inv<1, 1>(x, data, tid);
+        STAMP(5);
+        inv_pass<1>(x[0], tw, tid);
+        STAMP(6);
+        x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
+        exchange_inv<0, 1>(x, data, tid);
+        STAMP(7);
+        inv_pass<0>(x[0], tw, tid);
+        STAMP(8);
+#pragma unroll
+        for (int k = 0; k < E; k++) x[0][k] = reduce(x[0][k]);
+        STAMP(9);
+        // forward
+        fwd_pass<0>(x[0], tw, tid);
+        STAMP(10);
+        exchange_fwd<0, 1>(x, data, tid);
+        STAMP(11);
+        fwd_pass<1>(x[0], tw, tid);
+        STAMP(12);
+        exchange_fwd<1, 1>(x, data, tid);
+        STAMP(13);
+        fwd_pass<2>(x[0], tw, tid);
+        STAMP(14);
+        exchange_fwd<2, 1>(x, data, tid);
+        STAMP(15);
+        fwd_pass<3>(x[0], tw, tid);
+        STAMP(16);
+    }
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < E; k++) acc += x[0][k];
+    sink[blockIdx.x * T + tid] = acc;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Write-path elementwise steps.

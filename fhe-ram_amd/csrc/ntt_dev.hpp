@@ -71,18 +71,23 @@ __device__ __forceinline__ int pat(int tid, int k) {
     const int lo = tid & ((1 << LS) - 1);
     return (hi << (LS + LOGE)) + (k << LS) + lo;
 }
-// LDS layout of exchange X (between pass X and X+1).  The read side walks runs of
-// R = N >> LOGE*(X+2) consecutive elements; when R < 32 a pad of R per E*R block keeps both the
-// write side and the read side bank-conflict free.
+// LDS layout of exchange X (between pass X and X+1).  Every layout keeps the 64*E indices owned by
+// wave w inside the padded region [64*(E+1)*w, 64*(E+1)*(w+1)):
+//  * the read side of exchange X walks runs of R = N >> LOGE*(X+2) consecutive elements; for
+//    R < 64 a pad of R per E*R block keeps both sides bank-conflict free;
+//  * otherwise (runs of whole waves) a pad of 64 per 64*E block only aligns the regions.
 template <int X>
 __device__ __forceinline__ int lay(int idx) {
     constexpr int LR = LOGN - LOGE * (X + 2);  // log2(R)
-    if constexpr (LR >= 5) return idx;
+    if constexpr (LR >= 6) return idx + ((idx >> (6 + LOGE)) << 6);
     else return idx + ((idx >> (LR + LOGE)) << LR);
 }
+// Exchange X stays inside one wave when the pass-X pattern already has hi >= wave granularity
+// (S_X = N >> LOGE*(X+1) <= 64): thread t = 64w + l then touches only indices of region w before
+// and after, so no workgroup barrier is needed — LDS operations of one wave execute in order.
+template <int X>
+constexpr bool wave_local() { return (LOGN - LOGE * (X + 1)) <= 6; }
 
-// B polynomials are transformed together: one LDS exchange (two barriers) moves all of them, and
-// the B independent butterfly streams give the FP64 pipe the ILP that 2 waves/SIMD cannot.
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) and then
 // synchronises, but leaves global loads/stores in flight.  __syncthreads() also drains vmcnt,
 // which would serialise the operand prefetches and the output stores behind every exchange.
@@ -90,14 +95,21 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// B polynomials are transformed together: one LDS exchange moves all of them, and the B
+// independent butterfly streams give the FP64 pipe more ILP.
+// Hazard bookkeeping: positions of pattern 0 (lay<0>(tid + T*k)) are private to a thread.  The only
+// accesses that read what another WAVE wrote are (a) the pattern-1 side of exchange 0 and (b) the
+// automorphism gather in the key-switch kernel; a barrier separates each of them from the writes
+// before it, and a barrier at the first LDS write of every transform separates them from the
+// writes after it.
 template <int X, int B>
 __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, int tid) {
-    lds_barrier();  // previous readers of the buffer are done
+    if constexpr (!wave_local<X>()) lds_barrier();   // cross-wave readers of the previous transform are done
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X>(tid, k))] = x[b][k];
-    lds_barrier();
+    if constexpr (!wave_local<X>()) lds_barrier();
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
@@ -105,12 +117,14 @@ __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, in
 }
 template <int X, int B>
 __device__ __forceinline__ void exchange_inv(double (&x)[B][E], double* data, int tid) {
-    lds_barrier();
+    // no barrier before the write when everything since the fence at the start of ntt_inv was wave
+    // local; a second cross-wave exchange (radix 4 only) must fence the readers of the one before it
+    if constexpr (!wave_local<X>() && !wave_local<X + 1>()) lds_barrier();
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X + 1>(tid, k))] = x[b][k];
-    lds_barrier();
+    if constexpr (!wave_local<X>()) lds_barrier();
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
@@ -227,6 +241,7 @@ __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, dou
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+    lds_barrier();   // first LDS write of this transform: earlier cross-wave readers are done
     inv_rec<NPASS - 1, B>(x, tw, data, tid);
 #pragma unroll
     for (int b = 0; b < B; b++)
