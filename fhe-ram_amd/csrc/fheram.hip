@@ -89,6 +89,9 @@ struct fheram_ctx {
     int32_t* d_tmp = nullptr;      // [ws]
     int32_t* d_tmp2 = nullptr;     // [ws]
     int32_t* d_w = nullptr;        // [ws]
+    double* d_big = nullptr;       // [LIMB_SPLIT_MAX ciphertexts] un-normalised limbs of the limb-parallel path
+    double* d_big2 = nullptr;      // same, for launches on the side stream
+    int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel path
     int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo
     int32_t* d_gat[3] = {nullptr, nullptr, nullptr};   // [n_shards][ws] gathered partials + ping-pong (root)
     int nco = 0;                   // output columns per workgroup: 1 = split by column (2 workgroups per
@@ -206,6 +209,7 @@ int download_i64(fheram_ctx* c, int64_t* dst, const int32_t* src, size_t n) {
 }
 
 // ---- kernel launchers ---------------------------------------------------------------------
+constexpr int LIMB_SPLIT_MAX = 64;   // ciphertexts per launch the limb-parallel path is used for (at most)
 constexpr int EW_SLICES = 8;   // workgroups per ciphertext of the elementwise kernels (blockIdx.z)
 // One workgroup per ciphertext does the least work (no repeated forward transforms); splitting by
 // output column doubles the number of workgroups, which pays while the batch cannot fill the CUs.
@@ -218,16 +222,34 @@ void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly) {
     hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->cur, in, out, c->d_tw, c->ninv);
 }
 // res = a (x) ggsw over a (gx, gy) grid of ciphertexts; res must not alias a
+// Limb-parallel path: 2*SK workgroups per ciphertext + a normalisation pass, chosen while even the
+// column split leaves most CUs idle.
+double* big_of(const fheram_ctx* c) { return c->cur == c->stream2 ? c->d_big2 : c->d_big; }
+bool use_limb_split(const fheram_ctx* c, int gx, int gy, int sk) {
+    return c->limb_split && (long)gx * gy <= LIMB_SPLIT_MAX && (long)gx * gy * 2 * sk <= c->cus;
+}
 void launch_ep(fheram_ctx* c, GlweRef a, GlweRef res, const double* ggsw, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "ext_product", (uint64_t)gx * gy);
-    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_ext_product<3, 4, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw);
-    else hipLaunchKernelGGL((k_ext_product<3, 4, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw);
+    if (use_limb_split(c, gx, gy, 4)) {
+        hipLaunchKernelGGL((k_ext_product<3, 4, 1, 1>), dim3(gx, gy, 8), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+        hipLaunchKernelGGL((k_ext_product<3, 4, 1, 2>), dim3(gx, gy, 2), dim3(T), 0, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+        return;
+    }
+    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_ext_product<3, 4, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+    else hipLaunchKernelGGL((k_ext_product<3, 4, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
 }
 template <int MODE, int SX, int SK, int SO>
 void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "keyswitch", (uint64_t)gx * gy);
+    if (use_limb_split(c, gx, gy, SK)) {
+        KsArgs kb = ka;
+        kb.big = big_of(c);
+        hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1, 1>), dim3(gx, gy, 2 * SK), dim3(T), LDS_BYTES, c->cur, kb);
+        hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1, 2>), dim3(gx, gy, 2), dim3(T), 0, c->cur, kb);
+        return;
+    }
     if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);
     else hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ka);
 }
@@ -239,7 +261,7 @@ void launch_copy(fheram_ctx* c, GlweRef src, GlweRef dst, int gx, int gy) {
 KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* key, int64_t gal, int t = 0, int rot_mul = 0, int rot_base = 0) {
     KsArgs ka;
     ka.a = a; ka.b = b; ka.out = out; ka.key = key; ka.tw = c->d_tw;
-    ka.g = galois_mod(gal); ka.ginv = galois_inv_mod(ka.g); ka.t = t; ka.rot_mul = rot_mul; ka.rot_base = rot_base;
+    ka.g = galois_mod(gal); ka.ginv = galois_inv_mod(ka.g); ka.t = t; ka.rot_mul = rot_mul; ka.rot_base = rot_base; ka.big = c->d_big;
     return ka;
 }
 const double* trace_key(fheram_ctx* c, int i) { return c->d_atk + (size_t)i * fheram_ctx::ATK; }
@@ -565,6 +587,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipEventCreate(&c->t0));
     CCHK(hipEventCreate(&c->t1));
     {
+        const char* ls = getenv("FHERAM_LIMB_SPLIT");
+        c->limb_split = (ls && ls[0] == '0') ? 0 : 1;
         const char* e = getenv("FHERAM_NCO");
         c->nco = (e && e[0] == '2') ? 2 : ((e && e[0] == '1') ? 1 : 0);
         hipDeviceProp_t prop;
@@ -574,7 +598,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR(k_prepare);
     LDSATTR((&k_ext_product<3, 4, 1>));
     LDSATTR((&k_ext_product<3, 4, 2>));
-#define LDSATTR_KS(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>))
+    LDSATTR((&k_ext_product<3, 4, 1, 1>));
+#define LDSATTR_KS(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);
     LDSATTR_KS(KS_TRACE, 3, 4, 3);
     LDSATTR_KS(KS_PAIR, 3, 4, 3);
@@ -602,6 +627,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_ggsw_tmp2, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tmp2, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_part, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_big, (size_t)LIMB_SPLIT_MAX * BIG_STRIDE * sizeof(double)));
+    CCHK(hipMalloc(&c->d_big2, (size_t)LIMB_SPLIT_MAX * BIG_STRIDE * sizeof(double)));
     if (n_shards > 1) for (int i = 0; i < 3; i++) CCHK(hipMalloc(&c->d_gat[i], (size_t)n_shards * c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tree, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_res, (size_t)c->ws * G * sizeof(int32_t)));
@@ -627,7 +654,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -142,9 +142,39 @@ __device__ __forceinline__ void ep_mac(double (&acc)[E], const double (&x0)[SA][
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int SA, int SG, int NCO>
+// STAGE selects how a ciphertext operation is spread over workgroups:
+//   0  fused: one workgroup (NCO = 2) or one per output column (NCO = 1) does everything;
+//   1  limb-parallel, used when the batch is far too small to fill the chip (the dependent chain
+//      at the end of every RAM op has only word_size ciphertexts per round): blockIdx.z = (column,
+//      limb); the workgroup produces ONE un-normalised output limb polynomial into `big`;
+//   2  the normalisation / post-step pass over those limbs (blockIdx.z = column).
+// Stages 1+2 compute exactly the values stage 0 computes, in the same order per coefficient.
+constexpr int BIG_STRIDE = 2 * 5 * N;   // doubles of `big` per ciphertext: [column][limb <= 5][N]
+__device__ __forceinline__ long big_ct() { return ((long)blockIdx.y * gridDim.x + blockIdx.x) * BIG_STRIDE; }
+
+template <int SA, int SG, int NCO, int STAGE = 0>
 __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
-                                                            const double* __restrict__ tw_g) {
+                                                            const double* __restrict__ tw_g, double* __restrict__ big) {
+    if constexpr (STAGE == 2) {
+        const int tid = threadIdx.x;
+        const int co = (int)blockIdx.z;
+        int32_t* rp = at(res);
+        const double* bp = big + big_ct() + (long)co * SG * N;
+        double carry[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) carry[k] = 0.0;
+#pragma unroll
+        for (int j = SG - 1; j >= 0; j--) {
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const double v = bp[(long)j * N + tid + T * k] + carry[k];
+                const double cy = carry_of(v);
+                carry[k] = cy;
+                if (j < SA) rp[glwe_off(j, co) + tid + T * k] = (int)digit_of(v, cy);
+            }
+        }
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
@@ -175,6 +205,21 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
 #pragma unroll
             for (int k = 0; k < E; k++) x1[r][k] = (double)xi[r][k];
         fwd_all<SA>(x1, tw, data, tid);
+    }
+    if constexpr (STAGE == 1) {
+        const int co = (int)blockIdx.z / SG, j = SG - 1 - (int)blockIdx.z % SG;
+        OpRegs g[SA];
+#pragma unroll
+        for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + j) * 2 + co) * N, tid);
+        double acc[1][E];
+#pragma unroll
+        for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+        ep_mac<SA, SG>(acc[0], x0, x1, g, ggsw, j, co, -1, tid);
+        ntt_inv<1>(acc, tw, data, tid);
+        double* bp = big + big_ct() + (long)(co * SG + j) * N;
+#pragma unroll
+        for (int k = 0; k < E; k++) bp[tid + T * k] = acc[0][k];
+        return;
     }
 
 #pragma unroll 1
@@ -245,6 +290,7 @@ struct KsArgs {
     int t;               // KS_PAIR: rotation amount (N >> (level+1))
     int rot_mul;         // KS_TRACE: rho = -(rot_base + blockIdx.x * rot_mul)   (write path: ct_lo * X^-row;
     int rot_base;        //           row = shard + x * n_shards when the RAM is sharded by rows)
+    double* big;         // STAGE 1/2: un-normalised limb polynomials, BIG_STRIDE doubles per ciphertext
 };
 
 // sign * a[(limb, col)][src] for the coefficient at position i of rot(a, rho)
@@ -296,36 +342,39 @@ __device__ __forceinline__ int sel_limb(const int (&x)[4], int j) { return j == 
 // a time (MAC, paired inverse transform, body add, automorphism through LDS, post-step and one
 // normalisation step each), so the live state between limbs is just the carries.
 // NCO as in k_ext_product.  out must not alias a or b.
-template <int MODE, int SX, int SK, int SO, int NCO>
+template <int MODE, int SX, int SK, int SO, int NCO, int STAGE = 0>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = threadIdx.x;
     STAMP(0);
-    load_twiddles(tw, ka.tw, tid);
+    if constexpr (STAGE != 2) load_twiddles(tw, ka.tw, tid);
     STAMP(1);
     const int32_t* ap = at(ka.a);
     const int32_t* bp = (MODE == KS_PAIR) ? at(ka.b) : nullptr;
     int32_t* op = at(ka.out);
     constexpr int BODY_COL = (MODE == KS_TENSOR) ? 1 : 0;
-    const int co0 = (NCO == 1) ? (int)blockIdx.z : 0;
+    const int co0 = (STAGE == 1) ? (int)blockIdx.z / SK : ((NCO == 1 || STAGE == 2) ? (int)blockIdx.z : 0);
+    constexpr int NCOL = (STAGE == 0) ? NCO : 1;
 
     // Phase 1: mask column of x, all limbs, transformed
     double xh[SX][E];
+    if constexpr (STAGE != 2) {
 #pragma unroll
-    for (int k = 0; k < E; k++) {
-        int xm[SX];
-        load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
+        for (int k = 0; k < E; k++) {
+            int xm[SX];
+            load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
 #pragma unroll
-        for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
+            for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
+        }
+        STAMP(2);
+        fwd_all<SX>(xh, tw, data, tid);
+        STAMP(3);
     }
-    STAMP(2);
-    fwd_all<SX>(xh, tw, data, tid);
-    STAMP(3);
 
 #pragma unroll 1
-    for (int c = 0; c < NCO; c++) {
+    for (int c = 0; c < NCOL; c++) {
         const int co = co0 + c;
         // per-coefficient limbs needed by the post-step (and the body add) of this column
         int xa[E][SX];   // KS_TRACE/ADD/SUBNEG: x column co;  KS_PAIR: rsh1(rot(a,-t)+b) column co
@@ -425,6 +474,30 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             }
         };
 
+        if constexpr (STAGE == 1) {   // one un-normalised limb polynomial per workgroup
+            const int j = SK - 1 - (int)blockIdx.z % SK;
+            fetch(j);
+            double acc[1][E];
+            mac(acc[0], -1);
+            ntt_inv<1>(acc, tw, data, tid);
+            add_body(acc[0], j);
+            if constexpr (MODE != KS_TENSOR) permute(acc, std::integral_constant<int, 1>{});
+            double* bgp = ka.big + big_ct() + (long)(co * SK + j) * N;
+#pragma unroll
+            for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
+            return;
+        }
+        if constexpr (STAGE == 2) {   // normalisation / post-step over the stored limbs
+            const double* bgp = ka.big + big_ct() + (long)co * SK * N;
+#pragma unroll
+            for (int j = SK - 1; j >= 0; j--) {
+                double acc[E];
+#pragma unroll
+                for (int k = 0; k < E; k++) acc[k] = bgp[(long)j * N + tid + T * k];
+                emit(acc, j);
+            }
+            return;
+        }
         constexpr int REM = SK % BI;
         STAMP(4);
         fetch(SK - 1);
