@@ -247,7 +247,7 @@ void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
         KsArgs kb = ka;
         kb.big = big_of(c);
         hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1, 1>), dim3(gx, gy, 2 * SK), dim3(T), LDS_BYTES, c->cur, kb);
-        hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1, 2>), dim3(gx, gy, 2), dim3(T), 0, c->cur, kb);
+        hipLaunchKernelGGL((k_keyswitch_norm<MODE, SX, SK, SO>), dim3(gx, gy, 2 * (N / 256)), dim3(256), 0, c->cur, kb);
         return;
     }
     if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);

@@ -487,17 +487,6 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
             return;
         }
-        if constexpr (STAGE == 2) {   // normalisation / post-step over the stored limbs
-            const double* bgp = ka.big + big_ct() + (long)co * SK * N;
-#pragma unroll
-            for (int j = SK - 1; j >= 0; j--) {
-                double acc[E];
-#pragma unroll
-                for (int k = 0; k < E; k++) acc[k] = bgp[(long)j * N + tid + T * k];
-                emit(acc, j);
-            }
-            return;
-        }
         constexpr int REM = SK % BI;
         STAMP(4);
         fetch(SK - 1);
@@ -588,6 +577,51 @@ __global__ __launch_bounds__(T, T / 256) void k_ntt_probe(const double* __restri
     sink[blockIdx.x * T + tid] = acc;
 }
 #endif
+
+// Normalisation / post-step pass of the limb-parallel path (STAGE 2 of k_keyswitch): one thread per
+// coefficient, grid (x, y, 2 columns * N/256 slices).  Same per-coefficient arithmetic as the
+// `emit` step of the fused kernel.
+template <int MODE, int SX, int SK, int SO>
+__global__ __launch_bounds__(256) void k_keyswitch_norm(KsArgs ka) {
+    constexpr int SLICES = N / 256;
+    const int co = (int)blockIdx.z / SLICES;
+    const int i = ((int)blockIdx.z % SLICES) * 256 + (int)threadIdx.x;
+    GlweRef ra = ka.a, rb = ka.b, ro = ka.out;
+    const int32_t* ap = ra.p + (long)blockIdx.y * ra.sy + (long)blockIdx.x * ra.sx;
+    const int32_t* bp = (MODE == KS_PAIR) ? rb.p + (long)blockIdx.y * rb.sy + (long)blockIdx.x * rb.sx : nullptr;
+    int32_t* op = ro.p + (long)blockIdx.y * ro.sy + (long)blockIdx.x * ro.sx;
+    const double* bgp = ka.big + big_ct() + (long)co * SK * N + i;
+    double v_[SK];
+#pragma unroll
+    for (int j = 0; j < SK; j++) v_[j] = bgp[(long)j * N];
+    int xa[SX];
+    if constexpr (MODE == KS_PAIR) load_pair_sum<SX>(ka, ap, bp, co, i, xa);
+    else if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) load_x<MODE, SX>(ka, ap, bp, co, i, xa);
+    double carry = 0.0, carry2 = 0.0;
+#pragma unroll
+    for (int j = SK - 1; j >= 0; j--) {
+        double v = v_[j];
+        if constexpr (MODE == KS_TRACE || MODE == KS_ADD) { if (j < SX) v += (double)xa[j < SX ? j : 0]; }
+        if constexpr (MODE == KS_SUBNEG) v = (j < SX ? (double)xa[j < SX ? j : 0] : 0.0) - v;
+        v += carry;
+        const double cy = carry_of(v);
+        carry = cy;
+        if (j < SO) {
+            const double d = digit_of(v, cy);
+            if constexpr (MODE == KS_PAIR) {
+                const double v2 = (double)xa[j < SX ? j : 0] - d + carry2;
+                const double cy2 = carry_of(v2);
+                carry2 = cy2;
+                int dst = i + ka.t;
+                const bool ng = dst >= N;
+                if (ng) dst -= N;
+                op[glwe_off(j, co) + dst] = cneg((int)digit_of(v2, cy2), ng);
+            } else {
+                op[glwe_off(j, co) + i] = (int)d;
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // Write-path elementwise steps.
