@@ -179,7 +179,8 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = threadIdx.x;
-    load_twiddles(tw, tw_g, tid);
+    TwRegs twr;
+    twiddles_issue(twr, tw_g, tid);
     const int32_t* ap = at(a);
     int32_t* rp = at(res);
     const int co0 = (NCO == 1) ? (int)blockIdx.z : 0;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
         for (int r = 0; r < SA; r++)
 #pragma unroll
             for (int k = 0; k < E; k++) xi[r][k] = ap[glwe_off(r, 0) + tid + T * k];
+        twiddles_commit(twr, tw, tid);
 #pragma unroll
         for (int r = 0; r < SA; r++)
 #pragma unroll
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     double* data = lds + LDS_TW;
     const int tid = threadIdx.x;
     STAMP(0);
-    if constexpr (STAGE != 2) load_twiddles(tw, ka.tw, tid);
+    TwRegs twr;
+    twiddles_issue(twr, ka.tw, tid);
     STAMP(1);
     const int32_t* ap = at(ka.a);
     const int32_t* bp = (MODE == KS_PAIR) ? at(ka.b) : nullptr;
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll
             for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
         }
+        twiddles_commit(twr, tw, tid);
         STAMP(2);
         fwd_all<SX>(xh, tw, data, tid);
         STAMP(3);

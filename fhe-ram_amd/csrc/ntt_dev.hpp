@@ -255,6 +255,18 @@ __device__ __forceinline__ void load_twiddles(double* tw_lds, const double* __re
     for (int k = 0; k < E; k++) tw_lds[tid + T * k] = tw_g[tid + T * k];
     __syncthreads();
 }
+// the same in two halves, so that a kernel can issue its coefficient loads between them and pay
+// one global round trip instead of two at start-up
+struct TwRegs { double v[E]; };
+__device__ __forceinline__ void twiddles_issue(TwRegs& r, const double* __restrict__ tw_g, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) r.v[k] = tw_g[tid + T * k];
+}
+__device__ __forceinline__ void twiddles_commit(const TwRegs& r, double* tw_lds, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) tw_lds[tid + T * k] = r.v[k];
+    __syncthreads();
+}
 
 // ---- base-2^17 limb arithmetic on exact-integer doubles ------------------
 constexpr int BASE2K = 17;
