@@ -127,7 +127,8 @@ __device__ __forceinline__ void fwd_all(double (&x)[S][E], const double* tw, dou
 template <int SA, int SG>
 __device__ __forceinline__ void ep_mac(double (&acc)[E], const double (&x0)[SA][E], const double (&x1)[SA][E], OpRegs (&g)[SA],
                                        const double* __restrict__ ggsw, int j, int co, int jnext, int tid) {
-    // g holds the column_in 0 operands of limb j on entry and those of limb jnext on exit
+    // g holds the column_in 0 operands of limb j on entry (requested by ep_fetch0 after the previous
+    // inverse transform); the column_in 1 operands are fetched between the two halves of the MAC
 #pragma unroll
     for (int r = 0; r < SA; r++) mac_regs(acc, x0[r], g[r]);
 #pragma unroll
@@ -135,11 +136,13 @@ __device__ __forceinline__ void ep_mac(double (&acc)[E], const double (&x0)[SA][
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < SA; r++) mac_regs(acc, x1[r], g[r]);
-    if (jnext >= 0) {
-#pragma unroll
-        for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + jnext) * 2 + co) * N, tid);
-    }
+    (void)jnext;
     __builtin_amdgcn_sched_barrier(0);
+}
+template <int SA, int SG>
+__device__ __forceinline__ void ep_fetch0(OpRegs (&g)[SA], const double* __restrict__ ggsw, int j, int co, int tid) {
+#pragma unroll
+    for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + j) * 2 + co) * N, tid);
 }
 
 // STAGE selects how a ciphertext operation is spread over workgroups:
@@ -251,9 +254,11 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
             for (int b = 0; b < BI; b++) {
 #pragma unroll
                 for (int k = 0; k < E; k++) acc[b][k] = 0.0;
+                if (b > 0) ep_fetch0<SA, SG>(g, ggsw, j - b, co, tid);
                 ep_mac<SA, SG>(acc[b], x0, x1, g, ggsw, j - b, co, j - b - 1, tid);
             }
             ntt_inv<BI>(acc, tw, data, tid);
+            if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid);   // overlaps the normalisation step
 #pragma unroll
             for (int b = 0; b < BI; b++) emit(acc[b], j - b);
         }
@@ -399,8 +404,9 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll
         for (int k = 0; k < E; k++) { carry[k] = 0.0; carry2[k] = 0.0; }
 
-        // key operands are prefetched one step ahead: the loads for the next limb are issued right
-        // after a MAC and their latency hides behind the following MAC / inverse transform
+        // key operands of the next limb are requested right after the inverse transform of the current
+        // one, so their latency overlaps the permutation / post-step but they do not occupy 48 VGPRs
+        // during the transform (holding them across it cost more than it hid: measured)
         OpRegs g[SX];
         auto fetch = [&](int j) {
 #pragma unroll
@@ -409,9 +415,9 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
         auto mac = [&](double (&acc)[E], int jnext) {
 #pragma unroll
             for (int k = 0; k < E; k++) acc[k] = 0.0;
+            (void)jnext;
 #pragma unroll
             for (int r = 0; r < SX; r++) mac_regs(acc, xh[r], g[r]);
-            if (jnext >= 0) fetch(jnext);
             __builtin_amdgcn_sched_barrier(0);
         };
         // vec_znx_big_add_small_inplace of the body limbs (source coefficients)
@@ -499,9 +505,13 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             double acc[BI][E];
             STAMP(8 + 4 * (SK - 1 - j));
 #pragma unroll
-            for (int b = 0; b < BI; b++) mac(acc[b], j - b - 1);
+            for (int b = 0; b < BI; b++) {
+                if (b > 0) fetch(j - b);
+                mac(acc[b], j - b - 1);
+            }
             STAMP(9 + 4 * (SK - 1 - j));
             ntt_inv<BI>(acc, tw, data, tid);
+            if (j - BI >= 0) fetch(j - BI);   // next limb's operands: their latency overlaps the permutation / post-step
             STAMP(10 + 4 * (SK - 1 - j));
 #pragma unroll
             for (int b = 0; b < BI; b++) add_body(acc[b], j - b);
