@@ -270,7 +270,7 @@ def main():
                                              "(not part of the timed region: the events add this much to a step)",
                                      "ms_per_step_instrumented": instr_elapsed * 1e3 / args.steps}
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
         r, q, w = cpu_baseline(max_addr, 99)
         # the sample is 1 of `ws` sub-RAMs: scale by ws (prepare_inv is shared, <1 % of a write)
         cpu_step_s = ws * (r + q + w)
