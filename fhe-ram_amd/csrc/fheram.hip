@@ -91,10 +91,7 @@ struct fheram_ctx {
     int32_t* d_w = nullptr;        // [ws]
     double* d_big = nullptr;       // [LIMB_SPLIT_MAX ciphertexts] un-normalised limbs of the limb-parallel path
     double* d_big2 = nullptr;      // same, for launches on the side stream
-    double* d_bigB = nullptr;      // second buffer of the chained trace steps (main stream only)
-    int32_t* d_xd[2] = {nullptr, nullptr};   // [LIMB_SPLIT_MAX] GLWE digits: inputs x of the chained trace steps
     int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel path
-    int chain = 1;                 // FHERAM_CHAIN=0 disables the chained trace steps
     int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo
     int32_t* d_gat[3] = {nullptr, nullptr, nullptr};   // [n_shards][ws] gathered partials + ping-pong (root)
     int nco = 0;                   // output columns per workgroup: 1 = split by column (2 workgroups per
@@ -294,21 +291,6 @@ void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, const double
 // GLWE::trace(start, end): step i = rsh(1) then a += phi_{g_i}(KS(a)).
 // The first step may read its input rotated by X^-(x*rot_mul) (write path, ram.rs:621,629).
 void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start, int end, int gx, int gy, int rot_mul = 0, int rot_base = 0) {
-    if (c->chain && end - start >= 2 && c->cur == c->stream && use_limb_split(c, gx, gy, 4)) {
-        // tiny batch: chained limb-parallel steps, one launch per step + one normalisation at the end
-        double* bg[2] = {c->d_big, c->d_bigB};
-        for (int i = 0; i < end - start; i++) {
-            KsArgs ka = ks_args(c, src, src, dst, trace_key(c, start + i), c->gal[start + i], 0, i == 0 ? rot_mul : 0, i == 0 ? rot_base : 0);
-            ChainArgs ca{bg[(i + 1) & 1], c->d_xd[(i + 1) & 1], bg[i & 1], c->d_xd[i & 1]};
-            ProfScope ps(c, "keyswitch", (uint64_t)gx * gy);
-            if (i == 0) hipLaunchKernelGGL((k_trace_chain<true>), dim3(gx, gy, 8), dim3(T), LDS_BYTES, c->cur, ka, ca);
-            else hipLaunchKernelGGL((k_trace_chain<false>), dim3(gx, gy, 8), dim3(T), LDS_BYTES, c->cur, ka, ca);
-        }
-        const int last = (end - start - 1) & 1;
-        ProfScope ps(c, "elementwise", (uint64_t)gx * gy);
-        hipLaunchKernelGGL(k_trace_chain_norm, dim3(gx, gy, 2 * (N / 256)), dim3(256), 0, c->cur, dst, bg[last], c->d_xd[last]);
-        return;
-    }
     run_chain(c, end - start, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) {
         KsArgs ka = ks_args(c, in, in, out, trace_key(c, start + i), c->gal[start + i], 0, i == 0 ? rot_mul : 0, i == 0 ? rot_base : 0);
         launch_ks<KS_TRACE, 3, 4, 3>(c, ka, gx, gy);
@@ -607,8 +589,6 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     {
         const char* ls = getenv("FHERAM_LIMB_SPLIT");
         c->limb_split = (ls && ls[0] == '0') ? 0 : 1;
-        const char* ch = getenv("FHERAM_CHAIN");
-        c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* e = getenv("FHERAM_NCO");
         c->nco = (e && e[0] == '2') ? 2 : ((e && e[0] == '1') ? 1 : 0);
         hipDeviceProp_t prop;
@@ -619,8 +599,6 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product<3, 4, 1>));
     LDSATTR((&k_ext_product<3, 4, 2>));
     LDSATTR((&k_ext_product<3, 4, 1, 1>));
-    LDSATTR((&k_trace_chain<true>));
-    LDSATTR((&k_trace_chain<false>));
 #define LDSATTR_KS(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);
     LDSATTR_KS(KS_TRACE, 3, 4, 3);
@@ -651,8 +629,6 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_part, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_big, (size_t)LIMB_SPLIT_MAX * BIG_STRIDE * sizeof(double)));
     CCHK(hipMalloc(&c->d_big2, (size_t)LIMB_SPLIT_MAX * BIG_STRIDE * sizeof(double)));
-    CCHK(hipMalloc(&c->d_bigB, (size_t)LIMB_SPLIT_MAX * BIG_STRIDE * sizeof(double)));
-    for (int i = 0; i < 2; i++) CCHK(hipMalloc(&c->d_xd[i], (size_t)LIMB_SPLIT_MAX * fheram_ctx::GLWE * sizeof(int32_t)));
     if (n_shards > 1) for (int i = 0; i < 3; i++) CCHK(hipMalloc(&c->d_gat[i], (size_t)n_shards * c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tree, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_res, (size_t)c->ws * G * sizeof(int32_t)));
@@ -678,7 +654,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_bigB, c->d_xd[0], c->d_xd[1], c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -638,127 +638,6 @@ __global__ __launch_bounds__(256) void k_keyswitch_norm(KsArgs ka) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Chained trace steps for tiny batches (GLWE::trace on word_size ciphertexts, ram.rs:457,540,572).
-// A limb-parallel trace step leaves un-normalised limbs `big` (after phi) and the step's input
-// digits x; its result is out = normalize(big + x).  Instead of materialising `out` with a separate
-// pass, the NEXT step's workgroups rebuild exactly the digits they need (their 8 coefficients per
-// thread) from (big_prev, x_prev) while loading their input: x_cur = rsh1(normalize(big_prev + x_prev)).
-// One launch per step instead of two; `k_trace_chain_norm` materialises the last step.
-// blockIdx.z = (column, limb) as in STAGE 1.  Workgroup (co, limb 0) also publishes column co of
-// x_cur for the step after.
-// ---------------------------------------------------------------------------------------
-struct ChainArgs {
-    const double* big_prev;   // [ct][2][4][N]   (unused by the first step)
-    const int32_t* x_prev;    // [ct] GLWE digits (unused by the first step)
-    double* big_cur;
-    int32_t* x_cur;
-};
-__device__ __forceinline__ long chain_ct_glwe() { return ((long)blockIdx.y * gridDim.x + blockIdx.x) * (3 * 2 * N); }
-
-// x_cur limbs of column `col` at coefficient i
-template <bool FIRST>
-__device__ __forceinline__ void chain_load_x(const KsArgs& ka, const ChainArgs& ca, const int32_t* ap, int col, int i, int (&x)[3]) {
-    if constexpr (FIRST) {
-        load_x<KS_TRACE, 3>(ka, ap, nullptr, col, i, x);
-    } else {
-        const double* bp = ca.big_prev + big_ct() + (long)col * 4 * N + i;
-        const int32_t* xp = ca.x_prev + chain_ct_glwe();
-        double in_l[4], out_l[3];
-#pragma unroll
-        for (int l = 0; l < 4; l++) in_l[l] = bp[(long)l * N] + (l < 3 ? (double)xp[glwe_off(l, col) + i] : 0.0);
-        normalize_coeff<4, 3>(in_l, out_l);
-        int o[3];
-#pragma unroll
-        for (int l = 0; l < 3; l++) o[l] = (int)out_l[l];
-        rsh1_coeff<3>(o, x);
-    }
-}
-
-template <bool FIRST>
-__global__ __launch_bounds__(T, T / 256) void k_trace_chain(KsArgs ka, ChainArgs ca) {
-    constexpr int SX = 3, SK = 4;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* tw = lds;
-    double* data = lds + LDS_TW;
-    const int tid = threadIdx.x;
-    TwRegs twr;
-    twiddles_issue(twr, ka.tw, tid);
-    const int32_t* ap = FIRST ? at(ka.a) : nullptr;
-    const int co = (int)blockIdx.z / SK, j = SK - 1 - (int)blockIdx.z % SK;
-
-    // operands of this workgroup's limb: requested first, their latency hides behind the forward transforms
-    OpRegs g[SX];
-#pragma unroll
-    for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
-
-    double xh[SX][E];
-    int xbody[E];   // limb j of x_cur column 0 (body add), only for co == 0 && j < SX
-    int32_t* xo = ca.x_cur + chain_ct_glwe();
-#pragma unroll
-    for (int k = 0; k < E; k++) {
-        const int i = tid + T * k;
-        int xm[SX];
-        chain_load_x<FIRST>(ka, ca, ap, 1, i, xm);
-#pragma unroll
-        for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
-        if (co == 1 && j == 0) {
-#pragma unroll
-            for (int r = 0; r < SX; r++) xo[glwe_off(r, 1) + i] = xm[r];
-        }
-        xbody[k] = 0;
-        if (co == 0 && j < SX) {
-            int xb[SX];
-            chain_load_x<FIRST>(ka, ca, ap, 0, i, xb);
-            xbody[k] = sel_limb(xb, j);
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < SX; r++) xo[glwe_off(r, 0) + i] = xb[r];
-            }
-        }
-    }
-    twiddles_commit(twr, tw, tid);
-    fwd_all<SX>(xh, tw, data, tid);
-
-    double acc[1][E];
-#pragma unroll
-    for (int k = 0; k < E; k++) acc[0][k] = 0.0;
-#pragma unroll
-    for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
-    ntt_inv<1>(acc, tw, data, tid);
-#pragma unroll
-    for (int k = 0; k < E; k++) acc[0][k] += (double)xbody[k];
-    // phi_g through LDS (see k_keyswitch)
-#pragma unroll
-    for (int k = 0; k < E; k++) data[lay<0>(tid + T * k)] = acc[0][k];
-    lds_barrier();
-    double* bgp = ca.big_cur + big_ct() + (long)(co * SK + j) * N;
-    int sidx = (tid * ka.ginv) & (2 * N - 1);
-    const int sstep = (T * ka.ginv) & (2 * N - 1);
-#pragma unroll
-    for (int k = 0; k < E; k++) {
-        const bool ng = sidx >= N;
-        const double d = data[lay<0>(sidx & (N - 1))];
-        bgp[tid + T * k] = ng ? -d : d;
-        sidx = (sidx + sstep) & (2 * N - 1);
-    }
-}
-// out = normalize(big + x): materialises the result of the last chained step
-__global__ __launch_bounds__(256) void k_trace_chain_norm(GlweRef out, const double* __restrict__ big, const int32_t* __restrict__ xd) {
-    constexpr int SLICES = N / 256;
-    const int co = (int)blockIdx.z / SLICES;
-    const int i = ((int)blockIdx.z % SLICES) * 256 + (int)threadIdx.x;
-    int32_t* op = out.p + (long)blockIdx.y * out.sy + (long)blockIdx.x * out.sx;
-    const double* bp = big + big_ct() + (long)co * 4 * N + i;
-    const int32_t* xp = xd + chain_ct_glwe();
-    double in_l[4], out_l[3];
-#pragma unroll
-    for (int l = 0; l < 4; l++) in_l[l] = bp[(long)l * N] + (l < 3 ? (double)xp[glwe_off(l, co) + i] : 0.0);
-    normalize_coeff<4, 3>(in_l, out_l);
-#pragma unroll
-    for (int l = 0; l < 3; l++) op[glwe_off(l, co) + i] = (int)out_l[l];
-}
-
-// ---------------------------------------------------------------------------------------
 // Write-path elementwise steps.
 // ---------------------------------------------------------------------------------------
 // out = normalize(a - b + c)      (ram.rs:574-576 with b = trace(a), c = w;  ram.rs:617,625-626)
