@@ -64,6 +64,9 @@ class TorchComm:
         if self.device:
             out = self.torch.empty((self.world * n_glwe, glwe_len), dtype=self.torch.int32, device="cuda")
             self.dist.all_gather_into_tensor(out, buf)
+            # RCCL ran on torch's stream, the evaluator uses its own: finish the collective before the
+            # engine reads the gathered buffer (the engine synchronises its stream before handing `buf` over)
+            self.torch.cuda.synchronize()
             return out
         t = self.torch.from_numpy(buf)
         outs = [self.torch.empty_like(t) for _ in range(self.world)]
@@ -73,6 +76,7 @@ class TorchComm:
     def broadcast(self, buf, root: int):
         if self.device:
             self.dist.broadcast(buf, src=root)
+            self.torch.cuda.synchronize()
             return buf
         t = self.torch.from_numpy(buf)
         self.dist.broadcast(t, src=root)
