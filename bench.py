@@ -264,7 +264,10 @@ def main():
             fp64_per_block = 11 * 24576 * 8 + 24 * 4096 * 7
             out["roofline_valu"] = {"bound": "valu_fp64", "achieved": ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12,
                                     "peak": FP64_VALU_PEAK_TINSTR, "unit": "T FP64 instr/s",
-                                    "frac": ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR}
+                                    "frac": ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR,
+                                    "measured_issue_peak": 29.3,
+                                    "measured_issue_peak_source": "profiles/r01_valu_rate.txt (tools/valu_rate.hip: sustained v_fma_f64 = "
+                                                                  "4.8 cycles per wave-instruction per SIMD at 2.17 GHz shader clock)"}
         out["kernel_classes"] = {"keyswitch": ks, "ext_product": ep, "prepare": pr, "elementwise": el}
         out["kernel_timing_pass"] = {"what": "separate pass of the same K steps with per-launch HIP events on the launch stream "
                                              "(not part of the timed region: the events add this much to a step)",
