@@ -84,6 +84,14 @@ _SYMBOLS = [
     ("fheram_glwe_trace", C.c_int, [C.c_void_p, C.c_int, C.c_int, I64P, C.c_int, I64P]),
     ("fheram_glwe_pack", C.c_int, [C.c_void_p, I64P, C.c_int, I64P]),
     ("fheram_ggsw_automorphism_inv", C.c_int, [C.c_void_p, I64P, I64P]),
+    ("fheram_secret_create", C.c_int, [C.c_void_p, I64P, C.POINTER(C.c_void_p)]),
+    ("fheram_secret_destroy", None, [C.c_void_p]),
+    ("fheram_glwe_encrypt_sk", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, I64P, C.c_int, C.c_int, I64P, I64P, I64P]),
+    ("fheram_glwe_decrypt", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, I64P, I64P]),
+    ("fheram_ram_encrypt_sk", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, I64P, I64P]),
+    ("fheram_address_encrypt_sk", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, I64P, I64P, C.POINTER(C.c_void_p)]),
+    ("fheram_address_download", C.c_int, [C.c_void_p, C.c_void_p, I64P]),
+    ("fheram_keys_encrypt_sk", C.c_int, [C.c_void_p, C.c_void_p, I64P, I64P, I64P]),
     ("fheram_timer_begin", C.c_int, [C.c_void_p]),
     ("fheram_timer_end", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("fheram_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
@@ -221,6 +229,33 @@ class EvaluationKeysPrepared:
     def from_dict(cls, evk: Dict):
         return cls(evk["gal_els"], list(evk["atk_glwe"]), evk["atk_ggsw_inv"], evk["tsk"])
 
+    @classmethod
+    def encrypt_sk(cls, ram: "Ram", sk: "GLWESecret", source_xa, source_xe, keep_std: bool = False):
+        """EvaluationKeys::encrypt_sk (keys.rs:135-180) + prepare (keys.rs:57-71) on `ram`'s device.
+        The sources stay on the host: source_xa.uniform_limbs(count), source_xe.gaussian(count, scale)
+        are drawn in the reference's order (12 trace keys, tensor key, p = -1 key).  With keep_std the
+        std forms come back too, so the keys can be loaded into other contexts."""
+        p = ram.params
+        n, b2k = p.n(), p.basek()
+        s4, s5 = -(-p.k_evk_trace() // b2k), -(-p.k_evk_ggsw_inv() // b2k)
+        n4, n5 = p.log_n * p.dnum_ct(), 2 * p.dnum_ggsw()
+        mask = np.concatenate([source_xa.uniform_limbs(n4 * s4 * n), source_xa.uniform_limbs(n5 * s5 * n)])
+        noise = np.concatenate([source_xe.gaussian(n4 * n, noise_scale(p.k_evk_trace(), b2k)),
+                                source_xe.gaussian(n5 * n, noise_scale(p.k_evk_ggsw_inv(), b2k))])
+        L = library()
+        atk_len, inv_len = L.fheram_atk_len(ram._h), L.fheram_evk_inv_len(ram._h)
+        std = np.zeros(p.log_n * atk_len + 2 * inv_len, dtype=np.int64) if keep_std else None
+        ram._chk(L.fheram_keys_encrypt_sk(ram._h, sk._h, _p(mask), _p(noise), _p(std) if keep_std else None))
+        gal = galois_elements(p.log_n)
+        if keep_std:
+            o = p.log_n * atk_len
+            keys = cls(gal, [std[i * atk_len:(i + 1) * atk_len] for i in range(p.log_n)], std[o + inv_len:o + 2 * inv_len], std[o:o + inv_len])
+        else:
+            keys = cls.__new__(cls)
+            keys.gal_els, keys.atk_glwe, keys.atk_ggsw_inv, keys.tsk_ggsw_inv, keys.atk_ggsw_inv_p = _i64(gal), None, None, None, -1
+        ram._keys = keys   # already prepared on this context
+        return keys
+
 
 class Address:
     """address.rs:21-24: one Coordinate (list of GGSW digits) per Base1D of the plan."""
@@ -228,10 +263,40 @@ class Address:
     def __init__(self, params: Parameters, ggsw_digits):
         self.base2d = params.base2d()
         n_digits = self.base2d.as_1d().size()
-        self.digits = [_i64(g).ravel() for g in ggsw_digits]
-        if len(self.digits) != n_digits:
-            raise FheRamError(1, f"address needs {n_digits} GGSW digits, got {len(self.digits)}")
+        self._digits = [_i64(g).ravel() for g in ggsw_digits]
+        if len(self._digits) != n_digits:
+            raise FheRamError(1, f"address needs {n_digits} GGSW digits, got {len(self._digits)}")
         self._handles = {}  # ctx handle -> device address
+
+    @property
+    def digits(self):
+        """std-form GGSW digits on the host; an address encrypted on the device downloads them on first use"""
+        if self._digits is None:
+            h = next(iter(self._handles.values()))
+            n_digits = self.base2d.as_1d().size()
+            out = np.zeros((n_digits, h.ram.params.ggsw_len()), dtype=np.int64)
+            h.ram._chk(library().fheram_address_download(h.ram._h, h.h, _p(out)))
+            self._digits = [out[i] for i in range(n_digits)]
+        return self._digits
+
+    @classmethod
+    def encrypt_sk(cls, ram: "Ram", value: int, sk: "GLWESecret", source_xa, source_xe):
+        """Address::encrypt_sk (address.rs:86-109) on `ram`'s device with host-side sources (see
+        EvaluationKeysPrepared.encrypt_sk).  The GGSW digits never touch the host unless `.digits` is read."""
+        p = ram.params
+        self = cls.__new__(cls)
+        self.base2d = p.base2d()
+        n_digits = self.base2d.as_1d().size()
+        n, b2k = p.n(), p.basek()
+        size = -(-p.k_ggsw_addr() // b2k)
+        n_glwe = n_digits * p.dnum_ct() * 2
+        mask = source_xa.uniform_limbs(n_glwe * size * n)
+        noise = source_xe.gaussian(n_glwe * n, noise_scale(p.k_ggsw_addr(), b2k))
+        out = C.c_void_p()
+        ram._chk(library().fheram_address_encrypt_sk(ram._h, sk._h, int(value), _p(mask), _p(noise), C.byref(out)))
+        self._digits = None
+        self._handles = {id(ram): _AddrHandle(out.value, ram)}
+        return self
 
     @classmethod
     def alloc_from_params(cls, params: Parameters):  # address.rs:58
@@ -266,6 +331,48 @@ class _AddrHandle:
         if self.h and _LIB is not None:
             _LIB.fheram_address_destroy(self.h)
             self.h = None
+
+
+def cast_u8_to_signed(value: int, bit_length: int) -> int:
+    """examples/fhe-ram.rs:25-32"""
+    shift = 8 - bit_length
+    v = (value << shift) & 0xFF
+    v = v - 256 if v >= 128 else v
+    return v >> shift
+
+
+def encode_coeff(value: int, k: int, base2k: int = 17):
+    """encode_coeff_i64(value, k, idx): value * 2^-k on ceil(k/base2k) normalised limbs"""
+    size = -(-k // base2k)
+    x = value << (size * base2k - k)
+    limbs = [0] * size
+    for j in range(size - 1, -1, -1):
+        d = ((x + (1 << (base2k - 1))) % (1 << base2k)) - (1 << (base2k - 1))
+        limbs[j] = d
+        x = (x - d) >> base2k
+    return limbs
+
+
+def noise_scale(k: int, base2k: int = 17) -> float:
+    """Noise of a ciphertext at precision k sits on limb ceil(k/base2k)-1, scaled by 2^((limb+1)*base2k - k)
+    (Poulpy add_normal): the factor the host sampler multiplies sigma by."""
+    return float(1 << (-(-k // base2k) * base2k - k))
+
+
+class GLWESecret:
+    """GLWESecret + GLWESecretPrepared (examples/fhe-ram.rs:49-59) on a Ram's device: coefficients in {-1,0,1}."""
+
+    def __init__(self, ram: "Ram", sk):
+        self.ram = ram
+        self._h = None
+        out = C.c_void_p()
+        ram._chk(library().fheram_secret_create(ram._h, _p(_i64(sk)), C.byref(out)))
+        self._h = out.value
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.fheram_secret_destroy(self._h)
+            self._h = None
 
 
 class Ram:
@@ -326,6 +433,77 @@ class Ram:
         if rows.size != p.word_size() * self.local_rows() * p.glwe_len():
             raise FheRamError(1, f"invalid data: expected {p.word_size()}x{self.local_rows()} GLWE rows (ram.rs:144-155)")
         self._chk(library().fheram_ram_upload(self._h, _p(rows)))
+
+    def encrypt_sk(self, data, sk: GLWESecret, source_xa, source_xe):
+        """Ram::encrypt_sk (ram.rs:129-167) on the device.  data: max_addr*word_size bytes.  The sources are
+        host objects (uniform_limbs(count) / gaussian(count, scale)); draws are made for every row of the
+        RAM in the reference's order and a sharded context keeps those of its own rows."""
+        p = self.params
+        data = np.ascontiguousarray(data, dtype=np.uint8).ravel()
+        n, b2k = p.n(), p.basek()
+        size = -(-p.k_glwe_ct() // b2k)
+        ws, rows = p.word_size(), p.rows()
+        mask = source_xa.uniform_limbs(ws * rows * size * n).reshape(ws, rows, size * n)
+        noise = source_xe.gaussian(ws * rows * n, noise_scale(p.k_glwe_ct(), b2k)).reshape(ws, rows, n)
+        if self.n_shards > 1:
+            mask = np.ascontiguousarray(mask[:, self.shard::self.n_shards])
+            noise = np.ascontiguousarray(noise[:, self.shard::self.n_shards])
+        self._chk(library().fheram_ram_encrypt_sk(self._h, sk._h, data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size,
+                                                  _p(mask), _p(noise)))
+
+    def glwe_encrypt_sk(self, sk: GLWESecret, n_glwe: int, size: int, k: int, pt, pt_col: int, source_xa, source_xe):
+        """GLWE::encrypt_sk on n_glwe ciphertexts (examples/fhe-ram.rs:179-210); pt [n_glwe][pt_size][N] or None."""
+        n = self.params.n()
+        mask = source_xa.uniform_limbs(n_glwe * size * n)
+        noise = source_xe.gaussian(n_glwe * n, noise_scale(k, self.params.basek()))
+        out = np.zeros((n_glwe, size * 2 * n), dtype=np.int64)
+        pt_size = 0
+        if pt is not None:
+            pt = _i64(pt).reshape(n_glwe, -1, n)
+            pt_size = pt.shape[1]
+        self._chk(library().fheram_glwe_encrypt_sk(self._h, sk._h, n_glwe, size, k, _p(pt) if pt is not None else None,
+                                                   pt_size, pt_col, _p(mask), _p(noise), _p(out)))
+        return out
+
+    def glwe_decrypt(self, sk: GLWESecret, cts, size: int = 3):
+        """GLWE::decrypt (examples/fhe-ram.rs:217-222): normalised plaintext limbs [n_glwe][size][N]."""
+        n = self.params.n()
+        cts = _i64(cts).reshape(-1, size * 2 * n)
+        pt = np.zeros((cts.shape[0], size, n), dtype=np.int64)
+        self._chk(library().fheram_glwe_decrypt(self._h, sk._h, cts.shape[0], size, _p(cts), _p(pt)))
+        return pt
+
+    def encrypt_word(self, sk: GLWESecret, values, source_xa, source_xe):
+        """encrypt_glwe of the example (examples/fhe-ram.rs:179-210): one GLWE per byte, value on coefficient 0
+        at precision k_pt."""
+        p = self.params
+        values = [int(v) for v in values]
+        size_pt = -(-p.k_glwe_pt() // p.basek())
+        pt = np.zeros((len(values), size_pt, p.n()), dtype=np.int64)
+        for i, v in enumerate(values):
+            pt[i, :, 0] = encode_coeff(v, p.k_glwe_pt(), p.basek())
+        return self.glwe_encrypt_sk(sk, len(values), -(-p.k_glwe_ct() // p.basek()), p.k_glwe_ct(), pt, 0, source_xa, source_xe)
+
+    def decrypt_coeff(self, sk: GLWESecret, cts, wants, coeff: int = 0):
+        """decrypt_glwe + noise metric of the example (examples/fhe-ram.rs:212-237) for each ct:
+        returns [(value, log2 noise)]."""
+        p = self.params
+        k, b2k = p.k_glwe_ct(), p.basek()
+        size = -(-k // b2k)
+        pt = self.glwe_decrypt(sk, cts, size)
+        out = []
+        for limbs, want in zip(pt[:, :, coeff], wants):
+            res = 0
+            rem = b2k - (k % b2k)
+            for j in range(size):                       # decode_coeff_i64(k, coeff)
+                x = int(limbs[j])
+                res = (res << (b2k - rem)) + (x >> rem) if (j == size - 1 and rem != b2k) else (res << b2k) + x
+            log_scale = k - p.k_glwe_pt()                # :228
+            diff = res - (int(want) << log_scale)        # :230
+            noise = float(np.log2(abs(diff))) - k if diff != 0 else float("-inf")   # :231
+            mag = int(np.floor(abs(res) / (1 << log_scale) + 0.5))   # round half away from zero  :232-233
+            out.append((mag if res >= 0 else -mag, noise))
+        return out
 
     def store_encrypted(self) -> np.ndarray:
         p = self.params

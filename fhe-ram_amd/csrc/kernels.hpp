@@ -681,4 +681,62 @@ __global__ __launch_bounds__(256) void k_rotate(GlweRef a, GlweRef out, int rho)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Setup side: GLWE::encrypt_sk / decrypt with HOST-sampled randomness.
+// The host lays down a pre-ciphertext (body = plaintext limbs + the noise polynomial on its
+// limb, mask = the uniform limbs it drew); the workgroup replaces the body by
+//   DEC = 0:  normalise(body - mask * s)        GLWE::encrypt_sk        (ram.rs:369-376, coordinate.rs:161-168, keys.rs:158-173)
+//   DEC = 1:  normalise(body + mask * s)        GLWE::decrypt (phase)   (examples/fhe-ram.rs:217-222)
+// limb by limb from the least significant one (one forward + one inverse transform per limb,
+// only the carry survives).  pt1 != null (GGSW rows with col_in = 1, DEC = 0): the plaintext is
+// added to the MASK column after the product with s was taken, and the mask re-normalised.
+// s_hat: prepared secret (k_prepare).  One workgroup per ciphertext, in place.
+// ---------------------------------------------------------------------------------------
+template <int S, int DEC>
+__global__ __launch_bounds__(T, T / 256) void k_encrypt_sk(int32_t* __restrict__ cts, const double* __restrict__ s_hat,
+                                                           const double* __restrict__ tw_g, const int32_t* __restrict__ pt1) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    int32_t* cp = cts + (long)blockIdx.x * (S * 2 * N);
+    const int32_t* pp = pt1 ? pt1 + (long)blockIdx.x * (S * N) : nullptr;
+    OpRegs sh;
+    load_ops(sh, s_hat, tid);
+    double carry[E], carry_m[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) carry[k] = carry_m[k] = 0.0;
+#pragma unroll 1
+    for (int j = S - 1; j >= 0; j--) {
+        int32_t* body = cp + glwe_off(j, 0);
+        int32_t* mask = cp + glwe_off(j, 1);
+        int mi[E], bi[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) { mi[k] = mask[tid + T * k]; bi[k] = body[tid + T * k]; }
+        double x[1][E], acc[1][E];
+#pragma unroll
+        for (int k = 0; k < E; k++) { x[0][k] = (double)mi[k]; acc[0][k] = 0.0; }
+        ntt_fwd<1>(x, tw, data, tid);
+        mac_regs(acc[0], x[0], sh);
+        ntt_inv<1>(acc, tw, data, tid);
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const double v = (DEC ? (double)bi[k] + acc[0][k] : (double)bi[k] - acc[0][k]) + carry[k];
+            const double cy = carry_of(v);
+            carry[k] = cy;
+            body[tid + T * k] = (int)digit_of(v, cy);
+        }
+        if (pp) {
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const double v = (double)(mi[k] + pp[(long)j * N + tid + T * k]) + carry_m[k];
+                const double cy = carry_of(v);
+                carry_m[k] = cy;
+                mask[tid + T * k] = (int)digit_of(v, cy);
+            }
+        }
+    }
+}
+
 }  // namespace fk

@@ -149,6 +149,48 @@ int fheram_glwe_pack(fheram_ctx* ctx, const int64_t* cts, int count, int64_t* ou
 /* GGSW::automorphism(p=-1) + tensor-key row expansion (coordinate_prepared.rs:138). */
 int fheram_ggsw_automorphism_inv(fheram_ctx* ctx, const int64_t* ggsw_in, int64_t* ggsw_out);
 
+/* ---- Setup side on the device: secret-key encryption of the RAM, of
+ * addresses and of the evaluation keys, and decryption.  SAMPLING STAYS ON THE HOST: the caller
+ * draws the uniform mask limbs and the rounded-Gaussian noise polynomials from its own sources
+ * (Poulpy's `Source` in a Rust host: source_xa / source_xe of the calls cited below) and hands them
+ * over; the device does the arithmetic (products with the secret, limb normalisation, key
+ * preparation).  The same draws therefore give the same ciphertexts as the host implementation.
+ * Per GLWE of `size` limbs, in the order the reference encrypts them: mask = size*N limbs in
+ * [-2^16, 2^16) (limb-major), noise = N integers already scaled to the ciphertext precision k
+ * (added on limb ceil(k/base2k)-1; |e| < 2^30). */
+typedef struct fheram_secret fheram_secret;
+/* GLWESecret + GLWESecretPrepared (examples/fhe-ram.rs:49-59): sk = N coefficients in {-1,0,1}. */
+int fheram_secret_create(fheram_ctx* ctx, const int64_t* sk, fheram_secret** out);
+void fheram_secret_destroy(fheram_secret* sk);
+/* GLWE::encrypt_sk (Poulpy; call sites ram.rs:369-376, examples/fhe-ram.rs:179-210) on n_glwe
+ * ciphertexts of `size` limbs (3, 4 or 5) at precision k.  pt: [n_glwe][pt_size][N] normalised
+ * limbs or NULL (encryption of zero); pt_col 0 adds it to the body, 1 to the mask column after
+ * the product with the secret (GGSW rows).  out: [n_glwe][size][2][N]. */
+int fheram_glwe_encrypt_sk(fheram_ctx* ctx, const fheram_secret* sk, int n_glwe, int size, int k, const int64_t* pt,
+                           int pt_size, int pt_col, const int64_t* mask, const int64_t* noise, int64_t* out);
+/* GLWE::decrypt (examples/fhe-ram.rs:217-222): pt[i] = normalise(body + mask*s), [n_glwe][size][N]. */
+int fheram_glwe_decrypt(fheram_ctx* ctx, const fheram_secret* sk, int n_glwe, int size, const int64_t* ct, int64_t* pt);
+/* Ram::encrypt_sk (ram.rs:129-167, SubRam::encrypt_sk ram.rs:334-380): data = max_addr*word_size
+ * bytes, interleaved by word as in the reference.  mask [word_size][rows][3][N], noise
+ * [word_size][rows][N] for the rows THIS context holds (all of them unless sharded; a shard owns
+ * global rows shard + x*n_shards).  The rows are encrypted straight into device memory. */
+int fheram_ram_encrypt_sk(fheram_ctx* ctx, const fheram_secret* sk, const uint8_t* data, size_t data_len,
+                          const int64_t* mask, const int64_t* noise);
+/* Address::encrypt_sk (address.rs:86-109) -> Coordinate::encrypt_sk (coordinate.rs:121-180): GGSW
+ * digits of -value per coordinate.  mask [n_digits][3 rows][2 col_in][4][N], noise
+ * [n_digits][3][2][N], digits coordinate-major.  The address is created on the device. */
+int fheram_address_encrypt_sk(fheram_ctx* ctx, const fheram_secret* sk, uint32_t value, const int64_t* mask,
+                              const int64_t* noise, fheram_addr** out);
+/* The std-form GGSW digits of an address, [n_digits][fheram_ggsw_len] (parity tests, hand-over to a host). */
+int fheram_address_download(fheram_ctx* ctx, const fheram_addr* addr, int64_t* out);
+/* EvaluationKeys::encrypt_sk (keys.rs:135-180) + EvaluationKeysPrepared::prepare (keys.rs:57-71):
+ * the log2(N) trace keys in GLWE::trace_galois_elements order (3 rows of 4 limbs each), then the
+ * tensor key, then the p = -1 key (4 rows of 5 limbs each): mask = (36*4 + 8*5)*N limbs, noise =
+ * 44*N.  Keys are generated and prepared on the device; std_out (optional, may be NULL) receives
+ * the std forms [12][fheram_atk_len] ++ tensor [fheram_evk_inv_len] ++ inverse [fheram_evk_inv_len]. */
+int fheram_keys_encrypt_sk(fheram_ctx* ctx, const fheram_secret* sk, const int64_t* mask, const int64_t* noise,
+                           int64_t* std_out);
+
 /* ---- Measurement hooks (bench.py).  HIP events recorded on the context's own stream. */
 int fheram_timer_begin(fheram_ctx* ctx);
 int fheram_timer_end(fheram_ctx* ctx, float* elapsed_ms);

@@ -118,6 +118,44 @@ int fo_glwe_decrypt(void* c, const int64_t* ct, int64_t want, const int64_t* sk,
     decrypt_glwe(*(Ctx*)c, ct, want, sk, value, noise, coeff);
     FO_CATCH
 }
+// The oracle's sampler as a handle, so that a test can replay exactly the draws `fo_*_encrypt` make
+// from a seed (masks: one uniform limb per call; noise: Box-Muller with rejection) and hand them to
+// the device-side setup entry points (include/fheram.h, "Setup side on the device").
+void* fo_source_new(uint64_t seed) { return new Source(seed); }
+void fo_source_free(void* s) { delete (Source*)s; }
+void fo_source_uniform_limbs(void* s, int base2k, uint64_t count, int64_t* out) {
+    Source* x = (Source*)s;
+    for (uint64_t i = 0; i < count; i++) out[i] = x->uniform_limb(base2k);
+}
+void fo_source_gaussian(void* s, double sigma, double bound, uint64_t count, int64_t* out) {
+    Source* x = (Source*)s;
+    for (uint64_t i = 0; i < count; i++) out[i] = x->gaussian(sigma, bound);
+}
+double fo_sigma(void* c) { return ((Ctx*)c)->p.sigma; }
+// generic GLWE::encrypt_sk of `size` limbs at precision k; pt [pt_size][n] or null
+int fo_glwe_encrypt_sk(void* c, int size, int k, const int64_t* pt, int pt_size, int pt_col, const int64_t* sk,
+                       uint64_t seed_a, uint64_t seed_e, int64_t* ct) {
+    FO_TRY
+    Ctx* x = (Ctx*)c; Source xa(seed_a), xe(seed_e); PolyHat h; to_hat_prepared(x->ntt, sk, h);
+    glwe_encrypt_sk(*x, glwe_view(ct, x->n(), size), pt, pt_size, pt_col, h, k, xa, xe);
+    FO_CATCH
+}
+// phase: pt = normalise(body + mask * s), [size][n]
+int fo_glwe_phase(void* c, int size, const int64_t* ct, const int64_t* sk, int64_t* pt) {
+    FO_TRY
+    Ctx* x = (Ctx*)c; const int n = x->n();
+    VecView v = glwe_view(const_cast<int64_t*>(ct), n, size);
+    PolyHat h; to_hat_prepared(x->ntt, sk, h);
+    Big big(n, 1, size);
+    for (int j = 0; j < size; j++) {
+        poly_mul_small(*x, v.at(1, j), h, big.at(0, j));
+        int64_t* b = big.at(0, j); const int64_t* body = v.at(0, j);
+        for (int i = 0; i < n; i++) b[i] += body[i];
+    }
+    VecView pv{pt, n, 1, size};
+    big_normalize_col(*x, pv, 0, big, 0);
+    FO_CATCH
+}
 // generic GGSW encryption of a scalar polynomial (for op-level tests)
 int fo_ggsw_encrypt(void* c, const int64_t* scalar, const int64_t* sk, uint64_t seed_a, uint64_t seed_e, int64_t* out) {
     FO_TRY

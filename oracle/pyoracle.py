@@ -72,6 +72,15 @@ def lib():
         L.fo_glwe_encrypt_coeff0.argtypes = [C.c_void_p, C.c_uint8, I64P, C.c_uint64, C.c_uint64, I64P]
         L.fo_glwe_decrypt.argtypes = [C.c_void_p, I64P, C.c_int64, I64P, C.c_int, I64P, C.POINTER(C.c_double)]
         L.fo_ggsw_encrypt.argtypes = [C.c_void_p, I64P, I64P, C.c_uint64, C.c_uint64, I64P]
+        L.fo_source_new.restype = C.c_void_p
+        L.fo_source_new.argtypes = [C.c_uint64]
+        L.fo_source_free.argtypes = [C.c_void_p]
+        L.fo_source_uniform_limbs.argtypes = [C.c_void_p, C.c_int, C.c_uint64, I64P]
+        L.fo_source_gaussian.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint64, I64P]
+        L.fo_sigma.restype = C.c_double
+        L.fo_sigma.argtypes = [C.c_void_p]
+        L.fo_glwe_encrypt_sk.argtypes = [C.c_void_p, C.c_int, C.c_int, I64P, C.c_int, C.c_int, I64P, C.c_uint64, C.c_uint64, I64P]
+        L.fo_glwe_phase.argtypes = [C.c_void_p, C.c_int, I64P, I64P, I64P]
         L.fo_keys_prepare.restype = C.c_void_p
         L.fo_keys_prepare.argtypes = [C.c_void_p, I64P, C.c_int, I64P, I64P, I64P]
         L.fo_keys_free.argtypes = [C.c_void_p]
@@ -237,6 +246,31 @@ class Base2D:
         return self.as_1d().recomp(dec)
 
 
+class Source:
+    """The oracle's seeded sampler (oracle/setup.hpp `Source`) as the `source_xa` / `source_xe` object the
+    host mirror's encrypt_sk methods take: replaying a seed gives the draws `fo_*_encrypt(seed)` make."""
+
+    def __init__(self, seed, base2k=17, sigma=3.2):
+        self.h = lib().fo_source_new(seed)
+        self.base2k, self.sigma = base2k, sigma
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().fo_source_free(self.h)
+            self.h = None
+
+    def uniform_limbs(self, count):
+        out = np.zeros(count, dtype=np.int64)
+        lib().fo_source_uniform_limbs(self.h, self.base2k, count, _p(out))
+        return out
+
+    def gaussian(self, count, scale=1.0):
+        """round(N(0, (sigma*scale)^2)) truncated at 6 sigma*scale (Poulpy add_normal)"""
+        out = np.zeros(count, dtype=np.int64)
+        lib().fo_source_gaussian(self.h, self.sigma * scale, 6.0 * self.sigma * scale, count, _p(out))
+        return out
+
+
 class Oracle:
     """One oracle context (parameters + transform tables)."""
 
@@ -304,6 +338,25 @@ class Oracle:
         ct = np.ascontiguousarray(ct, dtype=np.int64)
         _chk(lib().fo_glwe_decrypt(self.h, _p(ct), want, _p(sk), coeff, C.byref(v), C.byref(nz)))
         return int(v.value), float(nz.value)
+
+    def glwe_encrypt_sk(self, size, k, pt, pt_col, sk, seed_a, seed_e):
+        """generic GLWE::encrypt_sk; pt [pt_size][n] or None"""
+        ct = np.zeros(size * 2 * self.p.n, dtype=np.int64)
+        if pt is not None:
+            pt = np.ascontiguousarray(pt, dtype=np.int64).reshape(-1, self.p.n)
+        _chk(lib().fo_glwe_encrypt_sk(self.h, size, k, _p(pt) if pt is not None else None, 0 if pt is None else pt.shape[0],
+                                      pt_col, _p(sk), seed_a, seed_e, _p(ct)))
+        return ct
+
+    def glwe_phase(self, ct, sk):
+        ct = np.ascontiguousarray(ct, dtype=np.int64)
+        size = ct.size // (2 * self.p.n)
+        pt = np.zeros((size, self.p.n), dtype=np.int64)
+        _chk(lib().fo_glwe_phase(self.h, size, _p(ct), _p(sk), _p(pt)))
+        return pt
+
+    def source(self, seed):
+        return Source(seed, self.p.base2k, float(lib().fo_sigma(self.h)))
 
     def ggsw_encrypt(self, scalar, sk, seed_a, seed_e):
         out = np.zeros(self.p.ggsw_len, dtype=np.int64)
