@@ -6,6 +6,7 @@
 //   EvaluationKeysPrepared  /root/reference/src/keys.rs:27-71
 //   Address                 /root/reference/src/address.rs:21-119
 //   Ram                     /root/reference/src/ram.rs:25-294
+//   GLWESecret, Source      setup side: the encrypt_sk methods take the caller's samplers (source_xa, source_xe)
 // The reference panics on misuse (assert!); these classes throw fheram::Error with the same text.
 #pragma once
 #include "../../include/fheram.h"
@@ -54,6 +55,18 @@ struct EvaluationKeysPrepared {
 };
 
 class Ram;
+
+// What the encrypt_sk methods need from a sampler (Poulpy's `Source` in the reference: source_xa for the
+// uniform masks, source_xe for the noise).  Sampling stays on the host; the device does the arithmetic.
+struct Source {
+    virtual ~Source() = default;
+    // `count` uniform limbs in [-2^(base2k-1), 2^(base2k-1))
+    virtual void uniform_limbs(int64_t* out, size_t count) = 0;
+    // `count` samples of round(N(0, (sigma*scale)^2)), truncated at 6 sigma*scale (Poulpy add_normal)
+    virtual void gaussian(int64_t* out, size_t count, double scale) = 0;
+};
+// noise of a ciphertext at precision k sits on limb ceil(k/base2k)-1, scaled by 2^((limb+1)*base2k - k)
+inline double noise_scale(uint32_t k, uint32_t base2k) { return (double)((uint64_t)1 << (((k + base2k - 1) / base2k) * base2k - k)); }
 
 // address.rs:21-24 — the GGSW digits of all coordinates, coordinate-major.
 class Address {
@@ -117,6 +130,61 @@ public:
         chk(fheram_write(ctx_, flat.data(), (int)w.size(), dev(address)));
     }
     bool state() const { return fheram_ram_state(ctx_) != 0; }                    // SubRam::state, ram.rs:302
+
+    // ---- setup side on the device (include/fheram.h, "Setup side on the device") -------------------
+    // GLWESecret + GLWESecretPrepared, examples/fhe-ram.rs:49-59
+    class Secret {
+    public:
+        Secret(Ram& ram, const std::vector<int64_t>& sk) : ram_(ram) { ram.chk(fheram_secret_create(ram.ctx_, sk.data(), &h_)); }
+        ~Secret() { if (h_) fheram_secret_destroy(h_); }
+        Secret(const Secret&) = delete;
+    private:
+        friend class Ram;
+        Ram& ram_;
+        fheram_secret* h_ = nullptr;
+    };
+    // Ram::encrypt_sk, ram.rs:129-167
+    void encrypt_sk(const std::vector<uint8_t>& data, const Secret& sk, Source& source_xa, Source& source_xe) {
+        const size_t n = params.n(), glwes = params.word_size() * fheram_rows(ctx_);
+        const size_t size = (params.k_glwe_ct() + params.basek() - 1) / params.basek();
+        std::vector<int64_t> mask(glwes * size * n), noise(glwes * n);
+        source_xa.uniform_limbs(mask.data(), mask.size());
+        source_xe.gaussian(noise.data(), noise.size(), noise_scale(params.k_glwe_ct(), params.basek()));
+        chk(fheram_ram_encrypt_sk(ctx_, sk.h_, data.data(), data.size(), mask.data(), noise.data()));
+    }
+    // Address::encrypt_sk, address.rs:86-109: the digits are created on the device
+    void encrypt_address(Address& a, uint32_t value, const Secret& sk, Source& source_xa, Source& source_xe) {
+        const size_t n = params.n(), size = (params.p.k_ggsw_addr + params.basek() - 1) / params.basek();
+        const size_t glwes = (size_t)fheram_n_digits(ctx_) * ((params.k_glwe_ct() + params.basek() - 1) / params.basek()) * 2;   // dnum_ct rows x 2
+        std::vector<int64_t> mask(glwes * size * n), noise(glwes * n);
+        source_xa.uniform_limbs(mask.data(), mask.size());
+        source_xe.gaussian(noise.data(), noise.size(), noise_scale(params.p.k_ggsw_addr, params.basek()));
+        if (a.h_) { fheram_address_destroy(a.h_); a.h_ = nullptr; }
+        chk(fheram_address_encrypt_sk(ctx_, sk.h_, value, mask.data(), noise.data(), &a.h_));
+        a.owner_ = this;
+    }
+    // EvaluationKeys::encrypt_sk + EvaluationKeysPrepared::prepare, keys.rs:135-180,57-71: generated and
+    // prepared on this context; `keys` is marked as the set in use (its std forms stay empty).
+    void encrypt_keys(EvaluationKeysPrepared& keys, const Secret& sk, Source& source_xa, Source& source_xe) {
+        const size_t n = params.n(), b = params.basek();
+        const size_t s4 = (params.p.k_evk_trace + b - 1) / b, s5 = (params.p.k_evk_ggsw_inv + b - 1) / b;
+        const size_t dnum_ct = (params.k_glwe_ct() + b - 1) / b, dnum_ggsw = (params.p.k_ggsw_addr + b - 1) / b;   // parameters.rs:273-279
+        const size_t n4 = params.p.log_n * dnum_ct, n5 = 2 * dnum_ggsw;
+        std::vector<int64_t> mask((n4 * s4 + n5 * s5) * n), noise((n4 + n5) * n);
+        source_xa.uniform_limbs(mask.data(), n4 * s4 * n);
+        source_xa.uniform_limbs(mask.data() + n4 * s4 * n, n5 * s5 * n);
+        source_xe.gaussian(noise.data(), n4 * n, noise_scale(params.p.k_evk_trace, params.basek()));
+        source_xe.gaussian(noise.data() + n4 * n, n5 * n, noise_scale(params.p.k_evk_ggsw_inv, params.basek()));
+        chk(fheram_keys_encrypt_sk(ctx_, sk.h_, mask.data(), noise.data(), nullptr));
+        keys_ = &keys;
+    }
+    // GLWE::decrypt (examples/fhe-ram.rs:217-222): normalised plaintext limbs [n][size][N]
+    std::vector<int64_t> decrypt(const std::vector<Glwe>& cts, const Secret& sk) {
+        std::vector<int64_t> flat, pt(cts.size() * glwe_len() / 2);
+        for (auto& g : cts) flat.insert(flat.end(), g.begin(), g.end());
+        chk(fheram_glwe_decrypt(ctx_, sk.h_, (int)cts.size(), (int)(glwe_len() / (2 * params.n())), flat.data(), pt.data()));
+        return pt;
+    }
 
 private:
     fheram_ctx* ctx_ = nullptr;

@@ -3,6 +3,12 @@
 #include "fheram.hpp"
 #include <cstdio>
 
+// a sampler with the interface the encrypt_sk methods take (a real host plugs in its own CSPRNG)
+struct ZeroSource : fheram::Source {
+    void uniform_limbs(int64_t* out, size_t count) override { for (size_t i = 0; i < count; i++) out[i] = 0; }
+    void gaussian(int64_t* out, size_t count, double) override { for (size_t i = 0; i < count; i++) out[i] = 0; }
+};
+
 int main() {
     fheram::Parameters p;
     if (p.max_addr() != (1u << 14) || p.word_size() != 4 || p.basek() != 17) return 2;   // parameters.rs:11-21
@@ -12,6 +18,24 @@ int main() {
         fheram::Address addr;
         try { ram.read(addr, keys); return 3; }                      // no keys, empty RAM: must throw
         catch (const fheram::Error& e) { std::printf("refused as the reference would: %s\n", e.what()); }
+        // setup side on the device: secret, keys, RAM and address, then one read and its decryption
+        ZeroSource xa, xe;
+        std::vector<int64_t> sk(p.n(), 0);
+        sk[1] = 1; sk[5] = -1;
+        fheram::Ram::Secret dsk(ram, sk);
+        ram.encrypt_keys(keys, dsk, xa, xe);
+        std::vector<uint8_t> data((size_t)(1 << 12) * 4);
+        for (size_t i = 0; i < data.size(); i++) data[i] = (uint8_t)(i * 7 + 3);
+        ram.encrypt_sk(data, dsk, xa, xe);
+        const uint32_t idx = 1234;
+        ram.encrypt_address(addr, idx, dsk, xa, xe);
+        std::vector<int64_t> pt = ram.decrypt(ram.read(addr, keys), dsk);
+        for (size_t i = 0; i < 4; i++) {                             // noiseless: limb 0 of coefficient 0 is the byte's low 3 bits << 14
+            const int64_t want = (int64_t)((int8_t)(uint8_t)(data[idx * 4 + i] << 5) >> 5) * (1 << 14);
+            const int64_t got = pt[i * 3 * p.n()];
+            if (((got - want) & ((1 << 17) - 1)) != 0) { std::printf("word %zu: got %lld want %lld\n", i, (long long)got, (long long)want); return 5; }
+        }
+        std::printf("device-side setup + read + decrypt: ok\n");
     } catch (const fheram::Error& e) {
         if (e.code != FHERAM_ERR_DEVICE) return 4;
         std::printf("no GPU: %s\n", e.what());

@@ -161,3 +161,21 @@ def test_example_flow_with_device_setup(po, max_addr):
     oram.load(ram.store_encrypted())
     got = oram.read(o.address_new(np.stack(addr.digits)), okeys)
     assert np.array_equal(got, ram.read(addr, keys))
+
+
+def test_cpp_host_mirror_runs_device_setup_flow(tmp_path):
+    """fhe-ram_amd/host/host_check.cpp: the C++ mirror sets up secret, keys, RAM and address on the device
+    (noiseless sampler), reads a word and decrypts it."""
+    import os
+    import shutil
+    import subprocess
+    pkg = load_package()
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_check")
+    libdir = os.path.dirname(pkg.library_path())
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-o", exe, os.path.join(root, "fhe-ram_amd", "host", "host_check.cpp"),
+                           "-L" + libdir, "-lfheram", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "device-side setup + read + decrypt: ok" in r.stdout, r.stdout + r.stderr
