@@ -1286,6 +1286,12 @@ int fheram_address_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, uint32_t v
     int rc = check_setup_args(c, sk, S, k);
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    {   // debug_assert!(self.base2d.max() > value) (address.rs:98)
+        unsigned bits = 0;
+        for (auto& b1 : c->base2d) for (int b : b1) bits += (unsigned)b;
+        if (bits < 32 && ((uint64_t)value >> bits) != 0)
+            return fail(c, FHERAM_ERR_INVALID_ARG, "self.base2d.max() > value (address.rs:98): address does not fit the digit plan");
+    }
     const size_t glen = fheram_ctx::GLWE4;
     const int n = c->n_digits * D * 2;
     std::vector<int32_t> pre((size_t)n * glen, 0), pt1((size_t)n * S * N, 0);

@@ -125,6 +125,8 @@ def test_setup_argument_errors(env, po):
         ram.glwe_encrypt_sk(dsk, 1, 3, 51, None, 0, Bad(), Bad())
     with pytest.raises(pkg.FheRamError, match="does not fit"):
         ram.glwe_encrypt_sk(dsk, 1, 3, 60, None, 0, o.source(1), o.source(2))
+    with pytest.raises(pkg.FheRamError, match=r"base2d.max\(\) > value"):      # address.rs:98
+        pkg.Address.encrypt_sk(ram, 1 << 14, dsk, o.source(1), o.source(2))
 
 
 @pytest.mark.parametrize("max_addr", [1 << 14, 1 << 16])
