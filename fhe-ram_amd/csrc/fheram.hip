@@ -92,6 +92,7 @@ struct fheram_ctx {
     double* d_big = nullptr;       // [LIMB_SPLIT_MAX ciphertexts] un-normalised limbs of the limb-parallel path
     double* d_big2 = nullptr;      // same, for launches on the side stream
     int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel path
+    int use_graph = 0;             // FHERAM_GRAPH=1: replay each op's launch sequence from a hipGraph (per address)
     int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo
     int32_t* d_gat[3] = {nullptr, nullptr, nullptr};   // [n_shards][ws] gathered partials + ping-pong (root)
     int nco = 0;                   // output columns per workgroup: 1 = split by column (2 workgroups per
@@ -117,6 +118,7 @@ struct fheram_addr {
     int32_t* d_ggsw;   // [n_digits] std-form GGSW, int32
     int n_digits;
     int device;
+    hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // captured launch sequences: read, read_prepare_write, write
 };
 
 struct fheram_secret {
@@ -365,6 +367,29 @@ void coordinate_prepare_inv(fheram_ctx* c, const fheram_addr* addr, int ci, int3
     launch_prepare(c, tmp, prep, d * (int)(fheram_ctx::GGSW / N));
 }
 
+// The launch sequence of an op is a pure function of (context, address, op): with FHERAM_GRAPH=1 it is
+// captured once per address into a hipGraph and replayed, instead of being re-enqueued kernel by kernel.
+template <typename F>
+int run_op(fheram_ctx* c, const fheram_addr* addr, int which, F&& enqueue) {
+    if (!c->use_graph || c->profile) return enqueue();
+    fheram_addr* a = const_cast<fheram_addr*>(addr);
+    if (!a->graph[which]) {
+        hipGraph_t g = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue();
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc != FHERAM_OK || e != hipSuccess) {
+            if (g) hipGraphDestroy(g);
+            return rc != FHERAM_OK ? rc : fail(c, FHERAM_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        }
+        const hipError_t e2 = hipGraphInstantiate(&a->graph[which], g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e2 != hipSuccess) { a->graph[which] = nullptr; return fail(c, FHERAM_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+    }
+    HIPCHK(c, hipGraphLaunch(a->graph[which], c->stream));
+    return FHERAM_OK;
+}
+
 int check_common(fheram_ctx* c, const fheram_addr* addr) {
     if (!c) return FHERAM_ERR_INVALID_ARG;
     if (!addr || addr->ctx != c) return fail(c, FHERAM_ERR_INVALID_ARG, "address does not belong to this context (layout mismatch, ram.rs:404)");
@@ -596,6 +621,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     {
         const char* ls = getenv("FHERAM_LIMB_SPLIT");
         c->limb_split = (ls && ls[0] == '0') ? 0 : 1;
+        const char* gr = getenv("FHERAM_GRAPH");
+        c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
         const char* e = getenv("FHERAM_NCO");
         c->nco = (e && e[0] == '2') ? 2 : ((e && e[0] == '1') ? 1 : 0);
         hipDeviceProp_t prop;
@@ -756,6 +783,7 @@ int fheram_address_create(fheram_ctx* c, const int64_t* const* ggsw, int n_ggsw,
 void fheram_address_destroy(fheram_addr* a) {
     if (!a) return;
     hipSetDevice(a->device);
+    for (auto& g : a->graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
     if (a->d_ggsw) hipFree(a->d_ggsw);   // hipFree waits for outstanding work on the buffer
     delete a;
 }
@@ -779,7 +807,7 @@ int fheram_read(fheram_ctx* c, const fheram_addr* addr, int64_t* out) {
     if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_read_partial / fheram_read_finish");
     if (c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
     HIPCHK(c, hipSetDevice(c->device));
-    rc = read_impl(c, addr, false);
+    rc = run_op(c, addr, 0, [&] { return read_impl(c, addr, false); });
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
     return out ? fheram_result_download(c, out) : FHERAM_OK;
@@ -790,8 +818,9 @@ int fheram_read_prepare_write(fheram_ctx* c, const fheram_addr* addr, int64_t* o
     if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_read_partial / fheram_read_finish");
     if (c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
     HIPCHK(c, hipSetDevice(c->device));
-    rc = read_impl(c, addr, true);
+    rc = run_op(c, addr, 1, [&] { return read_impl(c, addr, true); });
     if (rc != FHERAM_OK) return rc;
+    c->state = true;                                                                  // ram.rs:533
     HIPCHK(c, hipGetLastError());
     return out ? fheram_result_download(c, out) : FHERAM_OK;
 }
@@ -813,9 +842,11 @@ int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* ad
     if (w) { rc = fheram_word_stage(c, w, n_w); if (rc != FHERAM_OK) return rc; }
     else if (!c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
     if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_write_root / fheram_write_shard");
-    write_side_begin(c, addr);
-    rc = write_top(c, addr);
-    if (rc == FHERAM_OK) rc = write_rows(c, addr);
+    rc = run_op(c, addr, 2, [&] {
+        write_side_begin(c, addr);
+        int r2 = write_top(c, addr);
+        return r2 == FHERAM_OK ? write_rows(c, addr) : r2;
+    });
     if (rc != FHERAM_OK) return rc;
     c->state = false;
     HIPCHK(c, hipGetLastError());

@@ -129,7 +129,7 @@ def test_setup_argument_errors(env, po):
         pkg.Address.encrypt_sk(ram, 1 << 14, dsk, o.source(1), o.source(2))
 
 
-@pytest.mark.parametrize("max_addr", [1 << 14, 1 << 16])
+@pytest.mark.parametrize("max_addr", [1 << 14, 1 << 16, 1 << 21, 1 << 24])
 def test_example_flow_with_device_setup(po, max_addr):
     """examples/fhe-ram.rs:34-177 with every setup step on the device (host-side sources): keys, RAM and
     address are never seen by the host; only the words read back are decrypted (on the device too)."""
@@ -157,6 +157,8 @@ def test_example_flow_with_device_setup(po, max_addr):
     ram.write(ram.encrypt_word(dsk, value, o.source(7), o.source(8)), addr, keys)
     data[4 * idx:4 * idx + 4] = value
     check(ram.read(addr, keys), data)
+    if max_addr > (1 << 16):      # BASELINE.json configs[4] (2^21) and the largest RAM the digit plan allows (N^2 = 2^24):
+        return                    # the flow's own assertions are the check; the oracle would take minutes
     # and the device-made setup is the oracle's setup: the oracle reads the same word from the same state
     okeys = o.keys_prepare(o.evk_gen(sk, 1, 2))
     oram = o.ram_new()
