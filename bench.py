@@ -265,9 +265,9 @@ def main():
             out["roofline_valu"] = {"bound": "valu_fp64", "achieved": ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12,
                                     "peak": FP64_VALU_PEAK_TINSTR, "unit": "T FP64 instr/s",
                                     "frac": ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR,
-                                    "measured_issue_peak": 29.3,
-                                    "measured_issue_peak_source": "profiles/r01_valu_rate.txt (tools/valu_rate.hip: sustained v_fma_f64 = "
-                                                                  "4.8 cycles per wave-instruction per SIMD at 2.17 GHz shader clock)"}
+                                    "measured_issue_peak": 36.0,
+                                    "measured_issue_peak_source": "profiles/r01_valu_rate.txt (tools/valu_rate.hip: mulmod chains sustain 1.8 ns per "
+                                                                  "wave-instruction per SIMD at the 2.15 GHz clock of FP64 load)"}
         out["kernel_classes"] = {"keyswitch": ks, "ext_product": ep, "prepare": pr, "elementwise": el}
         out["kernel_timing_pass"] = {"what": "separate pass of the same K steps with per-launch HIP events on the launch stream "
                                              "(not part of the timed region: the events add this much to a step)",

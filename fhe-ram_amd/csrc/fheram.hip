@@ -226,9 +226,11 @@ int pick_nco(const fheram_ctx* c, int gx, int gy) {
     if (c->nco != 0) return c->nco;
     return ((long)gx * gy * 2 <= c->cus) ? 1 : 2;
 }
-void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly) {
+// gal != 0: automorphism key of Galois element gal, prepared as NTT(phi_gal(K)) (see k_prepare)
+void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly, int64_t gal = 0) {
     ProfScope ps(c, "prepare", npoly);
-    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->cur, in, out, c->d_tw, c->ninv);
+    const int ginv = gal == 0 ? 0 : galois_inv_mod(galois_mod(gal));
+    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->cur, in, out, c->d_tw, c->ninv, ginv);
 }
 // res = a (x) ggsw over a (gx, gy) grid of ciphertexts; res must not alias a
 // Limb-parallel path: 2*SK workgroups per ciphertext + a normalisation pass, chosen while even the
@@ -726,11 +728,11 @@ int fheram_keys_load(fheram_ctx* c, const int64_t* gal_els, int n_gal, const int
     int rc = FHERAM_OK;
     for (int i = 0; i < LOGN && rc == FHERAM_OK; i++) {
         rc = upload_i64(c, d_stage, atk_glwe[order[i]], fheram_ctx::ATK);
-        if (rc == FHERAM_OK) launch_prepare(c, d_stage, c->d_atk + (size_t)i * fheram_ctx::ATK, (int)(fheram_ctx::ATK / N));
+        if (rc == FHERAM_OK) launch_prepare(c, d_stage, c->d_atk + (size_t)i * fheram_ctx::ATK, (int)(fheram_ctx::ATK / N), c->gal[i]);
         hipStreamSynchronize(c->stream);
     }
     if (rc == FHERAM_OK) rc = upload_i64(c, d_stage, atk_ggsw_inv, fheram_ctx::EVK5);
-    if (rc == FHERAM_OK) { launch_prepare(c, d_stage, c->d_atk_inv, (int)(fheram_ctx::EVK5 / N)); hipStreamSynchronize(c->stream); }
+    if (rc == FHERAM_OK) { launch_prepare(c, d_stage, c->d_atk_inv, (int)(fheram_ctx::EVK5 / N), -1); hipStreamSynchronize(c->stream); }
     if (rc == FHERAM_OK) rc = upload_i64(c, d_stage, tsk, fheram_ctx::EVK5);
     if (rc == FHERAM_OK) { launch_prepare(c, d_stage, c->d_tsk, (int)(fheram_ctx::EVK5 / N)); hipStreamSynchronize(c->stream); }
     hipFree(d_stage);
@@ -1384,7 +1386,7 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     if (e != hipSuccess) { hipFree(d_stage); if (d_small) hipFree(d_small); return fail(c, FHERAM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     std::vector<int32_t> sk_out(N), ss(2 * N, 0), pre;
     // GGLWE of `scalar` (placed on limb r of row r) under the secret whose prepared form is `hat`
-    auto gglwe = [&](const int32_t* scalar, const double* hat, int rows, int S, int k, double* d_prepared, int64_t* std_dst) -> int {
+    auto gglwe = [&](const int32_t* scalar, const double* hat, int rows, int S, int k, double* d_prepared, int64_t* std_dst, int64_t gal) -> int {
         const size_t glen = (size_t)S * 2 * N;
         pre.assign((size_t)rows * glen, 0);
         for (int r = 0; r < rows; r++) {
@@ -1396,7 +1398,7 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
         mask += (size_t)rows * S * N; noise += (size_t)rows * N;
         int rc2 = encrypt_staged(c, hat, d_stage, pre, nullptr, rows, S);
         if (rc2 == FHERAM_OK && std_dst) rc2 = download_i64(c, std_dst, d_stage, (size_t)rows * glen);
-        if (rc2 == FHERAM_OK) { launch_prepare(c, d_stage, d_prepared, (int)((size_t)rows * glen / N)); hipStreamSynchronize(c->stream); }
+        if (rc2 == FHERAM_OK) { launch_prepare(c, d_stage, d_prepared, (int)((size_t)rows * glen / N), gal); hipStreamSynchronize(c->stream); }
         return rc2;
     };
     // key from s to phi_{p^-1}(s): phi_p(KS(a)) then decrypts under s (keys.rs:158-165,171-173)
@@ -1405,7 +1407,7 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
         hipMemcpyAsync(d_small, sk_out.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
         launch_prepare(c, d_small, d_hat, 1);
         hipStreamSynchronize(c->stream);   // sk_out is reused by the next key
-        return gglwe(sk->sk.data(), d_hat, rows, S, k, d_prepared, std_dst);
+        return gglwe(sk->sk.data(), d_hat, rows, S, k, d_prepared, std_dst, p);
     };
     for (int i = 0; i < LOGN && rc == FHERAM_OK; i++)
         rc = automorphism_key(c->gal[i], fheram_ctx::DNUM_CT, fheram_ctx::S_EVK, (int)c->p.k_evk_trace,
@@ -1419,7 +1421,7 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     }
     if (rc == FHERAM_OK)
         rc = gglwe(ss.data(), sk->d_hat, fheram_ctx::DNUM_GGSW, fheram_ctx::S_INV, (int)c->p.k_evk_ggsw_inv, c->d_tsk,
-                   std_out ? std_out + (size_t)LOGN * fheram_ctx::ATK : nullptr);
+                   std_out ? std_out + (size_t)LOGN * fheram_ctx::ATK : nullptr, 0);
     if (rc == FHERAM_OK)
         rc = automorphism_key(-1, fheram_ctx::DNUM_GGSW, fheram_ctx::S_INV, (int)c->p.k_evk_ggsw_inv, c->d_atk_inv,
                               std_out ? std_out + (size_t)LOGN * fheram_ctx::ATK + fheram_ctx::EVK5 : nullptr);

@@ -45,9 +45,12 @@ __device__ __forceinline__ long glwe_off(int limb, int col) { return (long)(limb
 
 // ---------------------------------------------------------------------------------------
 // k_prepare: forward transform of `npoly` small polynomials into prepared form.
+// ginv != 0: the polynomial is first mapped through phi_g (g = ginv^-1 mod 2N), i.e. the prepared
+// operand is NTT(phi_g(K)).  Automorphism keys are stored this way so that the key-switch can apply
+// phi_g to its INPUT instead of to every output limb:  phi_g(sum_r x_r * K_r) = sum_r phi_g(x_r) * phi_g(K_r).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(T) void k_prepare(const int32_t* __restrict__ in, double* __restrict__ out,
-                                               const double* __restrict__ tw_g, double ninv) {
+                                               const double* __restrict__ tw_g, double ninv, int ginv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
@@ -55,8 +58,17 @@ __global__ __launch_bounds__(T) void k_prepare(const int32_t* __restrict__ in, d
     load_twiddles(tw, tw_g, tid);
     const int32_t* src = in + (long)blockIdx.x * N;
     double x[1][E];
+    if (ginv == 0) {
 #pragma unroll
-    for (int k = 0; k < E; k++) x[0][k] = (double)src[tid + T * k];
+        for (int k = 0; k < E; k++) x[0][k] = (double)src[tid + T * k];
+    } else {   // destination i' takes +-source i, i = i' * ginv mod 2N (one-off gather at key load)
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const int s = ((tid + T * k) * ginv) & (2 * N - 1);
+            const int v = src[s & (N - 1)];
+            x[0][k] = (double)(s >= N ? -v : v);
+        }
+    }
     ntt_fwd<1>(x, tw, data, tid);
     double2* o = reinterpret_cast<double2*>(out + (long)blockIdx.x * N);
 #pragma unroll
@@ -345,9 +357,14 @@ __device__ __forceinline__ int sel_limb(const int (&x)[3], int j) { return j == 
 __device__ __forceinline__ int sel_limb(const int (&x)[4], int j) { return j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3])); }
 
 // Structure as k_ext_product: the SX mask limbs are transformed together and stay in registers; the
-// SK output limbs of each column are then streamed from the least significant one upwards, two at
-// a time (MAC, paired inverse transform, body add, automorphism through LDS, post-step and one
-// normalisation step each), so the live state between limbs is just the carries.
+// SK output limbs of each column are then streamed from the least significant one upwards (MAC,
+// inverse transform, body add, post-step and one normalisation step each), so the live state
+// between limbs is just the carries.
+// phi_g is applied on the INPUT side: phi_g(sum_r x_r * K_r + body) = sum_r phi_g(x_r) * phi_g(K_r) + phi_g(body),
+// the key being prepared as NTT(phi_g(K)) (k_prepare).  The pre-stepped mask limbs are staged in LDS
+// as int32 and gathered with the odd stride g^-1 (conflict free) before the forward transforms, and
+// the body limbs are staged once per ciphertext and gathered when they are added: two LDS gathers
+// of small integers per ciphertext instead of one permutation of every output limb.
 // NCO as in k_ext_product.  out must not alias a or b.
 template <int MODE, int SX, int SK, int SO, int NCO, int STAGE = 0>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
@@ -363,20 +380,63 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     const int32_t* bp = (MODE == KS_PAIR) ? at(ka.b) : nullptr;
     int32_t* op = at(ka.out);
     constexpr int BODY_COL = (MODE == KS_TENSOR) ? 1 : 0;
+    constexpr bool PHI = (MODE != KS_TENSOR);   // KS_TENSOR has g = 1
     const int co0 = (STAGE == 1) ? (int)blockIdx.z / SK : ((NCO == 1 || STAGE == 2) ? (int)blockIdx.z : 0);
     constexpr int NCOL = (STAGE == 0) ? NCO : 1;
+    // Staging areas in the exchange buffers: the mask limbs (int32) use the start of the area, before any
+    // transform; the body limbs, three 18-bit fields per 64-bit word, the buffers the inverse transforms
+    // (KBI at a time) leave alone.
+    constexpr int KBI = (SX <= 3) ? BI : 1;
+    constexpr int WPC = (SX + 2) / 3;   // packed words per coefficient
+    static_assert((size_t)WPC * N * 8 <= (size_t)(BMAX - KBI) * LDS_DATA * sizeof(double), "body staging does not fit");
+    int* mstage = reinterpret_cast<int*>(data);
+    unsigned long long* bstage = reinterpret_cast<unsigned long long*>(data + KBI * LDS_DATA);
+    auto stage_body = [&](const int (&v)[SX], int i) {
+#pragma unroll
+        for (int w = 0; w < WPC; w++) {
+            unsigned long long word = 0;
+#pragma unroll
+            for (int r = 3 * w; r < SX && r < 3 * w + 3; r++) word |= (unsigned long long)(unsigned)(v[r] + (1 << 17)) << (18 * (r - 3 * w));
+            bstage[w * N + i] = word;
+        }
+    };
+    // phi_g: destination i' = tid + T*k takes +-source i, i = i' * ginv mod 2N
+    const int sidx0 = (tid * ka.ginv) & (2 * N - 1);
+    const int sstep = (T * ka.ginv) & (2 * N - 1);
 
-    // Phase 1: mask column of x, all limbs, transformed
+    // Phase 1: mask column of x, all limbs, mapped through phi_g and transformed
     double xh[SX][E];
     if constexpr (STAGE != 2) {
+        if constexpr (PHI) {
 #pragma unroll
-        for (int k = 0; k < E; k++) {
-            int xm[SX];
-            load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
+            for (int k = 0; k < E; k++) {
+                int xm[SX];
+                load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
 #pragma unroll
-            for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
+                for (int r = 0; r < SX; r++) mstage[r * N + tid + T * k] = xm[r];
+            }
+            twiddles_commit(twr, tw, tid);   // its barrier also publishes the staged limbs
+            int sidx = sidx0;
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const bool ng = sidx >= N;
+                const int s = sidx & (N - 1);
+#pragma unroll
+                for (int r = 0; r < SX; r++) xh[r][k] = (double)cneg(mstage[r * N + s], ng);
+                sidx = (sidx + sstep) & (2 * N - 1);
+            }
+            // the first exchange of the forward transform starts with a barrier: every gather is done
+            // before the staging area is overwritten
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                int xm[SX];
+                load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
+#pragma unroll
+                for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
+            }
+            twiddles_commit(twr, tw, tid);
         }
-        twiddles_commit(twr, tw, tid);
         STAMP(2);
         fwd_all<SX>(xh, tw, data, tid);
         STAMP(3);
@@ -385,19 +445,31 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll 1
     for (int c = 0; c < NCOL; c++) {
         const int co = co0 + c;
-        // per-coefficient limbs needed by the post-step (and the body add) of this column
+        // per-coefficient limbs needed by the post-step of this column
         int xa[E][SX];   // KS_TRACE/ADD/SUBNEG: x column co;  KS_PAIR: rsh1(rot(a,-t)+b) column co
-        int xb[E][SX];   // body limbs of x (column 0), only used when co == BODY_COL
+        int xb[E][SX];   // KS_TENSOR: body limbs of x (column 0), added to column 1
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const int i = tid + T * k;
-            if constexpr (MODE == KS_PAIR) {
-                load_pair_sum<SX>(ka, ap, bp, co, i, xa[k]);
-                load_x<MODE, SX>(ka, ap, bp, 0, i, xb[k]);
-            } else if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) {
-                load_x<MODE, SX>(ka, ap, bp, co, i, xa[k]);   // for co == 0 this is also the body
-            } else {
-                load_x<MODE, SX>(ka, ap, bp, 0, i, xb[k]);
+            if constexpr (MODE == KS_PAIR) load_pair_sum<SX>(ka, ap, bp, co, i, xa[k]);
+            else if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) load_x<MODE, SX>(ka, ap, bp, co, i, xa[k]);
+            else if constexpr (MODE == KS_TENSOR) load_x<MODE, SX>(ka, ap, bp, 0, i, xb[k]);
+        }
+        if constexpr (PHI) {
+            if (co == BODY_COL) {   // stage the body limbs of x (natural order) for the gathers of add_body
+                lds_barrier();      // slower waves may still be inside the wave-local exchanges of the forward transforms
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    const int i = tid + T * k;
+                    if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) {
+                        stage_body(xa[k], i);   // column 0 of x is the body
+                    } else {
+                        int xm[SX];
+                        load_x<MODE, SX>(ka, ap, bp, 0, i, xm);
+                        stage_body(xm, i);
+                    }
+                }
+                // published by the barriers of the first inverse transform, which precede every gather
             }
         }
         double carry[E], carry2[E];
@@ -405,8 +477,8 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
         for (int k = 0; k < E; k++) { carry[k] = 0.0; carry2[k] = 0.0; }
 
         // key operands of the next limb are requested right after the inverse transform of the current
-        // one, so their latency overlaps the permutation / post-step but they do not occupy 48 VGPRs
-        // during the transform (holding them across it cost more than it hid: measured)
+        // one, so their latency overlaps the post-step but they do not occupy 48 VGPRs during the
+        // transform (holding them across it cost more than it hid: measured)
         OpRegs g[SX];
         auto fetch = [&](int j) {
 #pragma unroll
@@ -420,13 +492,21 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             for (int r = 0; r < SX; r++) mac_regs(acc, xh[r], g[r]);
             __builtin_amdgcn_sched_barrier(0);
         };
-        // vec_znx_big_add_small_inplace of the body limbs (source coefficients)
+        // vec_znx_big_add_small_inplace of the body limbs, seen through phi_g
         auto add_body = [&](double (&acc)[E], int j) {
             if (co == BODY_COL && j < SX) {
+                if constexpr (PHI) {
+                    const int w = j >= 3 ? 1 : 0, sh = 18 * (j - 3 * w);
+                    int sidx = sidx0;
 #pragma unroll
-                for (int k = 0; k < E; k++) {
-                    if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) acc[k] += (double)sel_limb(xa[k], j);
-                    else acc[k] += (double)sel_limb(xb[k], j);
+                    for (int k = 0; k < E; k++) {
+                        const int v = (int)((bstage[w * N + (sidx & (N - 1))] >> sh) & 0x3FFFF) - (1 << 17);
+                        acc[k] += (double)cneg(v, sidx >= N);
+                        sidx = (sidx + sstep) & (2 * N - 1);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < E; k++) acc[k] += (double)sel_limb(xb[k], j);
                 }
             }
         };
@@ -459,31 +539,6 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             }
         };
 
-        // phi_g: destination i' takes +-source i, i = i' * ginv mod 2N (odd stride: conflict free).
-        // The write goes to this thread's own pattern-0 positions (no barrier needed before it); the
-        // gather reads other waves' data, so one barrier in between.
-        auto permute = [&](auto& acc, auto nb) {
-            constexpr int NB = decltype(nb)::value;
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<0>(tid + T * k)] = acc[b][k];
-            lds_barrier();
-            int sidx = (tid * ka.ginv) & (2 * N - 1);
-            const int sstep = (T * ka.ginv) & (2 * N - 1);
-#pragma unroll
-            for (int k = 0; k < E; k++) {
-                const bool ng = sidx >= N;
-                const int s = lay<0>(sidx & (N - 1));
-#pragma unroll
-                for (int b = 0; b < NB; b++) {
-                    const double d = data[b * LDS_DATA + s];
-                    acc[b][k] = ng ? -d : d;
-                }
-                sidx = (sidx + sstep) & (2 * N - 1);
-            }
-        };
-
         if constexpr (STAGE == 1) {   // one un-normalised limb polynomial per workgroup
             const int j = SK - 1 - (int)blockIdx.z % SK;
             fetch(j);
@@ -491,34 +546,32 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             mac(acc[0], -1);
             ntt_inv<1>(acc, tw, data, tid);
             add_body(acc[0], j);
-            if constexpr (MODE != KS_TENSOR) permute(acc, std::integral_constant<int, 1>{});
             double* bgp = ka.big + big_ct() + (long)(co * SK + j) * N;
 #pragma unroll
             for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
             return;
         }
-        constexpr int REM = SK % BI;
+        constexpr int REM = SK % KBI;
         STAMP(4);
         fetch(SK - 1);
 #pragma unroll 1
-        for (int j = SK - 1; j >= BI - 1 + REM; j -= BI) {
-            double acc[BI][E];
+        for (int j = SK - 1; j >= KBI - 1 + REM; j -= KBI) {
+            double acc[KBI][E];
             STAMP(8 + 4 * (SK - 1 - j));
 #pragma unroll
-            for (int b = 0; b < BI; b++) {
+            for (int b = 0; b < KBI; b++) {
                 if (b > 0) fetch(j - b);
                 mac(acc[b], j - b - 1);
             }
             STAMP(9 + 4 * (SK - 1 - j));
-            ntt_inv<BI>(acc, tw, data, tid);
-            if (j - BI >= 0) fetch(j - BI);   // next limb's operands: their latency overlaps the permutation / post-step
+            ntt_inv<KBI>(acc, tw, data, tid);
+            if (j - KBI >= 0) fetch(j - KBI);   // next limb's operands: their latency overlaps the post-step
             STAMP(10 + 4 * (SK - 1 - j));
 #pragma unroll
-            for (int b = 0; b < BI; b++) add_body(acc[b], j - b);
-            if constexpr (MODE != KS_TENSOR) permute(acc, std::integral_constant<int, BI>{});
+            for (int b = 0; b < KBI; b++) add_body(acc[b], j - b);
             STAMP(11 + 4 * (SK - 1 - j));
 #pragma unroll
-            for (int b = 0; b < BI; b++) emit(acc[b], j - b);
+            for (int b = 0; b < KBI; b++) emit(acc[b], j - b);
         }
         STAMP(5);
         if constexpr (REM == 1) {
@@ -526,7 +579,6 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             mac(acc[0], -1);
             ntt_inv<1>(acc, tw, data, tid);
             add_body(acc[0], 0);
-            if constexpr (MODE != KS_TENSOR) permute(acc, std::integral_constant<int, 1>{});
             emit(acc[0], 0);
         }
     }
@@ -549,40 +601,40 @@ __global__ __launch_bounds__(T, T / 256) void k_ntt_probe(const double* __restri
         for (int k = 0; k < E; k++) x[0][k] = reduce(x[0][k]);
         lds_barrier();
         STAMP(1);
-        inv_pass<3>(x[0], tw, tid);
+        { TwPass t_; inv_twiddles<3>(t_, tw, tid); inv_pass<3>(x[0], t_); }
         STAMP(2);
         x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
         exchange_inv<2, 1>(x, data, tid);
         STAMP(3);
-        inv_pass<2>(x[0], tw, tid);
+        { TwPass t_; inv_twiddles<2>(t_, tw, tid); inv_pass<2>(x[0], t_); }
         STAMP(4);
         x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
         exchange_inv<1, 1>(x, data, tid);
         STAMP(5);
-        inv_pass<1>(x[0], tw, tid);
+        { TwPass t_; inv_twiddles<1>(t_, tw, tid); inv_pass<1>(x[0], t_); }
         STAMP(6);
         x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
         exchange_inv<0, 1>(x, data, tid);
         STAMP(7);
-        inv_pass<0>(x[0], tw, tid);
+        { TwPass t_; inv_twiddles<0>(t_, tw, tid); inv_pass<0>(x[0], t_); }
         STAMP(8);
 #pragma unroll
         for (int k = 0; k < E; k++) x[0][k] = reduce(x[0][k]);
         STAMP(9);
         // forward
-        fwd_pass<0>(x[0], tw, tid);
+        { TwPass t_; fwd_twiddles<0>(t_, tw, tid); fwd_pass<0>(x[0], t_); }
         STAMP(10);
         exchange_fwd<0, 1>(x, data, tid);
         STAMP(11);
-        fwd_pass<1>(x[0], tw, tid);
+        { TwPass t_; fwd_twiddles<1>(t_, tw, tid); fwd_pass<1>(x[0], t_); }
         STAMP(12);
         exchange_fwd<1, 1>(x, data, tid);
         STAMP(13);
-        fwd_pass<2>(x[0], tw, tid);
+        { TwPass t_; fwd_twiddles<2>(t_, tw, tid); fwd_pass<2>(x[0], t_); }
         STAMP(14);
         exchange_fwd<2, 1>(x, data, tid);
         STAMP(15);
-        fwd_pass<3>(x[0], tw, tid);
+        { TwPass t_; fwd_twiddles<3>(t_, tw, tid); fwd_pass<3>(x[0], t_); }
         STAMP(16);
     }
     double acc = 0;

@@ -147,17 +147,31 @@ __device__ __forceinline__ void gs(double& a, double& b, double w) {
 
 // Twiddle table position of W[2^s + J] (s = LOGE*Q + u, J = hi*2^u + j): 2^s + j*E^Q + hi, so
 // the lanes of a wave read consecutive (last pass) or identical (first passes) addresses.
+// The E-1 twiddles of a pass are read into registers as one group, issued BEFORE the exchange that
+// precedes the pass: LDS operations complete in order, so by the time the exchanged data has
+// arrived the twiddles are there too.  (Read one by one next to their butterflies, as the compiler
+// schedules them when left alone, every read exposes a full LDS round trip: measured at 40 % of
+// an inverse transform.)
+struct TwPass { double w[E - 1]; };
 template <int Q>
-__device__ __forceinline__ void fwd_pass(double (&x)[E], const double* tw, int tid) {
+__device__ __forceinline__ void fwd_twiddles(TwPass& t, const double* tw, int tid) {
     constexpr int LS = LOGN - LOGE * (Q + 1);
     constexpr int HQ = 1 << (LOGE * Q);
     const int hi = tid >> LS;
+#pragma unroll
+    for (int u = 0; u < LOGE; u++)
+#pragma unroll
+        for (int j = 0; j < (1 << u); j++) t.w[(1 << u) - 1 + j] = tw[(HQ << u) + j * HQ + hi];
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int Q>
+__device__ __forceinline__ void fwd_pass(double (&x)[E], const TwPass& t) {
 #pragma unroll
     for (int u = 0; u < LOGE; u++) {
         const int half = E >> (u + 1);
 #pragma unroll
         for (int j = 0; j < (1 << u); j++) {
-            const double w = tw[(HQ << u) + j * HQ + hi];
+            const double w = t.w[(1 << u) - 1 + j];
 #pragma unroll
             for (int i = 0; i < half; i++) bf(x[2 * j * half + i], x[2 * j * half + i + half], w);
         }
@@ -166,16 +180,24 @@ __device__ __forceinline__ void fwd_pass(double (&x)[E], const double* tw, int t
 // inverse of fwd_pass<Q> up to the factor E (the total 1/N is folded into prepared operands):
 // w^-1 of forward twiddle W[m + J] is -W[2m - 1 - J]; the sign is absorbed by using (b - a).
 template <int Q>
-__device__ __forceinline__ void inv_pass(double (&x)[E], const double* tw, int tid) {
+__device__ __forceinline__ void inv_twiddles(TwPass& t, const double* tw, int tid) {
     constexpr int LS = LOGN - LOGE * (Q + 1);
     constexpr int HQ = 1 << (LOGE * Q);
     const int hm = HQ - 1 - (tid >> LS);
+#pragma unroll
+    for (int u = LOGE - 1; u >= 0; u--)
+#pragma unroll
+        for (int j = 0; j < (1 << u); j++) t.w[(1 << u) - 1 + j] = tw[(HQ << u) + ((1 << u) - 1 - j) * HQ + hm];
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int Q>
+__device__ __forceinline__ void inv_pass(double (&x)[E], const TwPass& t) {
 #pragma unroll
     for (int u = LOGE - 1; u >= 0; u--) {
         const int half = E >> (u + 1);
 #pragma unroll
         for (int j = 0; j < (1 << u); j++) {
-            const double w = tw[(HQ << u) + ((1 << u) - 1 - j) * HQ + hm];
+            const double w = t.w[(1 << u) - 1 + j];
 #pragma unroll
             for (int i = 0; i < half; i++) gs(x[2 * j * half + i], x[2 * j * half + i + half], w);
         }
@@ -193,9 +215,9 @@ __device__ __forceinline__ void inv_pass(double (&x)[E], const double* tw, int t
 //    thread.  Reducing slots 0 and 1 after each pass keeps I <= 2p, the next slot 0 below
 //    E*2p = 16p < 32p and every difference that feeds a product below 16p.
 template <int Q, int B>
-__device__ __forceinline__ void fwd_rec(double (&x)[B][E], const double* tw, double* data, int tid) {
+__device__ __forceinline__ void fwd_rec(double (&x)[B][E], const TwPass& t, const double* tw, double* data, int tid) {
 #pragma unroll
-    for (int b = 0; b < B; b++) fwd_pass<Q>(x[b], tw, tid);
+    for (int b = 0; b < B; b++) fwd_pass<Q>(x[b], t);
     if constexpr (Q + 1 < NPASS) {
         if constexpr (LOGE >= 4) {   // radix 16: a pass adds up to 3.6p; keep the classic per-pass reduce
 #pragma unroll
@@ -203,14 +225,16 @@ __device__ __forceinline__ void fwd_rec(double (&x)[B][E], const double* tw, dou
 #pragma unroll
                 for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
         }
+        TwPass tn;
+        fwd_twiddles<Q + 1>(tn, tw, tid);
         exchange_fwd<Q, B>(x, data, tid);
-        fwd_rec<Q + 1, B>(x, tw, data, tid);
+        fwd_rec<Q + 1, B>(x, tn, tw, data, tid);
     }
 }
 template <int Q, int B>
-__device__ __forceinline__ void inv_rec(double (&x)[B][E], const double* tw, double* data, int tid) {
+__device__ __forceinline__ void inv_rec(double (&x)[B][E], const TwPass& t, const double* tw, double* data, int tid) {
 #pragma unroll
-    for (int b = 0; b < B; b++) inv_pass<Q>(x[b], tw, tid);
+    for (int b = 0; b < B; b++) inv_pass<Q>(x[b], t);
     if constexpr (Q > 0) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
@@ -222,8 +246,10 @@ __device__ __forceinline__ void inv_rec(double (&x)[B][E], const double* tw, dou
                 for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
             }
         }
+        TwPass tn;
+        inv_twiddles<Q - 1>(tn, tw, tid);
         exchange_inv<Q - 1, B>(x, data, tid);
-        inv_rec<Q - 1, B>(x, tw, data, tid);
+        inv_rec<Q - 1, B>(x, tn, tw, data, tid);
     }
 }
 
@@ -231,7 +257,9 @@ __device__ __forceinline__ void inv_rec(double (&x)[B][E], const double* tw, dou
 // out: x[b][k] = transform value at position E*tid + k (bit-reversed order), |x| < 11p.
 template <int B>
 __device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, double* data, int tid) {
-    fwd_rec<0, B>(x, tw, data, tid);
+    TwPass t;
+    fwd_twiddles<0>(t, tw, tid);
+    fwd_rec<0, B>(x, t, tw, data, tid);
 }
 // Inverse negacyclic NTT without the 1/N factor.  in: x[b][k] at position E*tid + k, |x| < 16p.
 // out: x[b][k] = N * coefficient(tid + T*k) mod p, centred in [-p/2, p/2].
@@ -241,8 +269,10 @@ __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, dou
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+    TwPass t;
+    inv_twiddles<NPASS - 1>(t, tw, tid);
     lds_barrier();   // first LDS write of this transform: earlier cross-wave readers are done
-    inv_rec<NPASS - 1, B>(x, tw, data, tid);
+    inv_rec<NPASS - 1, B>(x, t, tw, data, tid);
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll

@@ -1,0 +1,221 @@
+// Measurement tool (not part of the product): steady-state cost of one inverse transform of
+// csrc/ntt_dev.hpp on one CU (one 512-thread workgroup per CU, as in the evaluator), with parts of it
+// switched off to see what bounds it.   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I../fhe-ram_amd/csrc
+#include "ntt_dev.hpp"
+#include <cstdio>
+#include <vector>
+using namespace fk;
+
+// VARIANT 0: full ntt_inv<B>;  1: no workgroup barriers;  2: no LDS exchanges (butterflies + twiddle reads only);
+//         3: exchanges only (no butterflies)
+template <int B, int VARIANT>
+__global__ __launch_bounds__(T, T / 256) void k_bench(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    if constexpr (VARIANT == 5) { if (tid >= T / 2) __builtin_amdgcn_s_setprio(3); }
+    if constexpr (VARIANT == 6) { if ((tid >> 6) & 1) __builtin_amdgcn_s_setprio(3); }
+    double x[B][E];
+    for (int b = 0; b < B; b++)
+        for (int k = 0; k < E; k++) x[b][k] = (double)(tid * 8 + k + b);
+    for (int r = 0; r < reps; r++) {
+        if constexpr (VARIANT == 0 || VARIANT == 5 || VARIANT == 6) {
+            ntt_inv<B>(x, tw, data, tid);
+        } else {
+            for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+            TwPass t;
+            if constexpr (VARIANT != 3) { inv_twiddles<3>(t, tw, tid); for (int b = 0; b < B; b++) inv_pass<3>(x[b], t); }
+            if constexpr (VARIANT != 2) exchange_inv<2, B>(x, data, tid);
+            if constexpr (VARIANT != 3) { inv_twiddles<2>(t, tw, tid); for (int b = 0; b < B; b++) inv_pass<2>(x[b], t); }
+            if constexpr (VARIANT != 2) exchange_inv<1, B>(x, data, tid);
+            if constexpr (VARIANT != 3) { inv_twiddles<1>(t, tw, tid); for (int b = 0; b < B; b++) inv_pass<1>(x[b], t); }
+            if constexpr (VARIANT != 2) {
+                // exchange 0 with or without its barrier
+                for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<0>(pat<1>(tid, k))] = x[b][k];
+                if constexpr (VARIANT != 1) lds_barrier();   // VARIANT 7 = this barrier only (no barrier at the start of the transform)
+                for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = data[b * LDS_DATA + lay<0>(pat<0>(tid, k))];
+            }
+            if constexpr (VARIANT != 3) { inv_twiddles<0>(t, tw, tid); for (int b = 0; b < B; b++) inv_pass<0>(x[b], t); }
+            for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+        }
+    }
+    double s = 0;
+    for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) s += x[b][k];
+    sink[blockIdx.x * T + tid] = s;
+}
+
+// Two transforms software-pipelined inside each wave: while the exchange of one is in flight in the LDS
+// pipe, the butterflies of the other occupy the VALU.
+__device__ __forceinline__ void slots01(double (&x)[E]) { x[0] = reduce(x[0]); x[1] = reduce(x[1]); }
+template <int X> __device__ __forceinline__ void xchg_issue_local(double (&x)[E], double* buf, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) buf[lay<X>(pat<X + 1>(tid, k))] = x[k];
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = buf[lay<X>(pat<X>(tid, k))];
+}
+__global__ __launch_bounds__(T, T / 256) void k_pipe2(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    double* bufA = data;
+    double* bufB = data + LDS_DATA;
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    double a[E], b[E];
+    for (int k = 0; k < E; k++) { a[k] = (double)(tid * 8 + k); b[k] = (double)(tid * 8 + k + 1); }
+    for (int r = 0; r < reps; r++) {
+        for (int k = 0; k < E; k++) { a[k] = reduce(a[k]); b[k] = reduce(b[k]); }
+        TwPass t3, t2, t1, t0;
+        inv_twiddles<3>(t3, tw, tid);
+        lds_barrier();
+        inv_pass<3>(a, t3); slots01(a);
+        inv_twiddles<2>(t2, tw, tid);
+        xchg_issue_local<2>(a, bufA, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        inv_pass<3>(b, t3); slots01(b);
+        xchg_issue_local<2>(b, bufB, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        inv_pass<2>(a, t2); slots01(a);
+        inv_twiddles<1>(t1, tw, tid);
+        xchg_issue_local<1>(a, bufA, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        inv_pass<2>(b, t2); slots01(b);
+        xchg_issue_local<1>(b, bufB, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        inv_pass<1>(a, t1); slots01(a);
+        inv_twiddles<0>(t0, tw, tid);
+#pragma unroll
+        for (int k = 0; k < E; k++) bufA[lay<0>(pat<1>(tid, k))] = a[k];
+        __builtin_amdgcn_sched_barrier(0);
+        inv_pass<1>(b, t1); slots01(b);
+#pragma unroll
+        for (int k = 0; k < E; k++) bufB[lay<0>(pat<1>(tid, k))] = b[k];
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < E; k++) a[k] = bufA[lay<0>(pat<0>(tid, k))];
+#pragma unroll
+        for (int k = 0; k < E; k++) b[k] = bufB[lay<0>(pat<0>(tid, k))];
+        __builtin_amdgcn_sched_barrier(0);
+        inv_pass<0>(a, t0);
+        inv_pass<0>(b, t0);
+        for (int k = 0; k < E; k++) { a[k] = reduce(a[k]); b[k] = reduce(b[k]); }
+    }
+    double s = 0;
+    for (int k = 0; k < E; k++) s += a[k] + b[k];
+    sink[blockIdx.x * T + tid] = s;
+}
+#define MIX()                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) {               \
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);            \
+        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);            \
+    }
+__global__ __launch_bounds__(T, T / 256) void k_pipe2g(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    double* bufA = data;
+    double* bufB = data + LDS_DATA;
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    double a[E], b[E];
+    for (int k = 0; k < E; k++) { a[k] = (double)(tid * 8 + k); b[k] = (double)(tid * 8 + k + 1); }
+    for (int r = 0; r < reps; r++) {
+        for (int k = 0; k < E; k++) { a[k] = reduce(a[k]); b[k] = reduce(b[k]); }
+        TwPass t3, t2, t1, t0;
+        inv_twiddles<3>(t3, tw, tid);
+        lds_barrier();
+        inv_pass<3>(a, t3); slots01(a);
+        inv_twiddles<2>(t2, tw, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        xchg_issue_local<2>(a, bufA, tid);
+        inv_pass<3>(b, t3); slots01(b);
+        MIX();
+        __builtin_amdgcn_sched_barrier(0);
+        xchg_issue_local<2>(b, bufB, tid);
+        inv_pass<2>(a, t2); slots01(a);
+        MIX();
+        __builtin_amdgcn_sched_barrier(0);
+        inv_twiddles<1>(t1, tw, tid);
+        xchg_issue_local<1>(a, bufA, tid);
+        inv_pass<2>(b, t2); slots01(b);
+        MIX();
+        __builtin_amdgcn_sched_barrier(0);
+        xchg_issue_local<1>(b, bufB, tid);
+        inv_pass<1>(a, t1); slots01(a);
+        MIX();
+        __builtin_amdgcn_sched_barrier(0);
+        inv_twiddles<0>(t0, tw, tid);
+#pragma unroll
+        for (int k = 0; k < E; k++) bufA[lay<0>(pat<1>(tid, k))] = a[k];
+        __builtin_amdgcn_sched_barrier(0);
+        inv_pass<1>(b, t1); slots01(b);
+#pragma unroll
+        for (int k = 0; k < E; k++) bufB[lay<0>(pat<1>(tid, k))] = b[k];
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < E; k++) a[k] = bufA[lay<0>(pat<0>(tid, k))];
+#pragma unroll
+        for (int k = 0; k < E; k++) b[k] = bufB[lay<0>(pat<0>(tid, k))];
+        __builtin_amdgcn_sched_barrier(0);
+        inv_pass<0>(a, t0);
+        inv_pass<0>(b, t0);
+        for (int k = 0; k < E; k++) { a[k] = reduce(a[k]); b[k] = reduce(b[k]); }
+    }
+    double s = 0;
+    for (int k = 0; k < E; k++) s += a[k] + b[k];
+    sink[blockIdx.x * T + tid] = s;
+}
+template <typename K> void run_pipe2(K kern, const char* name, const double* tw, double* sink, int blocks) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    const int reps = 400;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 20; i++) kern<<<blocks, T, LDS_BYTES>>>(tw, sink, reps);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < 10; i++) kern<<<blocks, T, LDS_BYTES>>>(tw, sink, reps);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    printf("%-44s B=2 blocks=%4d: %7.3f us per transform per CU\n", name, blocks, ms * 1e3 / (10.0 * reps * 2));
+}
+
+template <int B, int VARIANT> void run(const char* name, const double* tw, double* sink, int blocks) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bench<B, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    const int reps = 400;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 20; i++) k_bench<B, VARIANT><<<blocks, T, LDS_BYTES>>>(tw, sink, reps);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < 10; i++) k_bench<B, VARIANT><<<blocks, T, LDS_BYTES>>>(tw, sink, reps);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double waves = (blocks + 255) / 256;   // workgroups per CU, sequential (LDS allows one at a time)
+    printf("%-44s B=%d blocks=%4d: %7.3f us per transform per CU\n", name, B, blocks, ms * 1e3 / (10.0 * reps * B * waves));
+}
+
+int main() {
+    std::vector<double> h(N);
+    for (int i = 0; i < N; i++) h[i] = (double)((i * 2654435761u) % 1000003);   // any values: timing only
+    double *tw, *sink;
+    hipMalloc(&tw, N * sizeof(double)); hipMalloc(&sink, 512 * T * sizeof(double));
+    hipMemcpy(tw, h.data(), N * sizeof(double), hipMemcpyHostToDevice);
+    run<1, 0>("inverse transform, full", tw, sink, 256);
+    run<1, 1>("  without the workgroup barrier", tw, sink, 256);
+    run<1, 2>("  butterflies + twiddle reads only", tw, sink, 256);
+    run<1, 3>("  exchanges only", tw, sink, 256);
+    run<1, 7>("  exchange-0 barrier only (double buffered)", tw, sink, 256);
+    run<2, 7>("  exchange-0 barrier only (double buffered)", tw, sink, 256);
+    run<1, 5>("  full, waves 4-7 at high priority", tw, sink, 256);
+    run<1, 6>("  full, odd waves at high priority", tw, sink, 256);
+    run<2, 0>("inverse transform, full", tw, sink, 256);
+    run<2, 2>("  butterflies + twiddle reads only", tw, sink, 256);
+    run<2, 3>("  exchanges only", tw, sink, 256);
+    run<3, 0>("inverse transform, full", tw, sink, 256);
+    run<3, 2>("  butterflies + twiddle reads only", tw, sink, 256);
+    run<3, 3>("  exchanges only", tw, sink, 256);
+    run_pipe2(k_pipe2, "two transforms, coarse pipeline", tw, sink, 256);
+    run_pipe2(k_pipe2g, "two transforms, DS ops spread over VALU", tw, sink, 256);
+    hipFree(tw); hipFree(sink);
+    return 0;
+}

@@ -59,6 +59,38 @@ __global__ void __launch_bounds__(512) k_clock(double* out, unsigned long long* 
   if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// dependent-chain behaviour at the evaluator's occupancy: one 512-thread workgroup per CU (2 waves/SIMD),
+// CH independent mulmod-like chains per thread (mul, fma, mul, rndne, fma, add: each op depends on the previous)
+template <int CH> __global__ void __launch_bounds__(512) k_chain(double* out, int iters) {
+  double v[CH];
+  for (int i = 0; i < CH; ++i) v[i] = 1.5 + threadIdx.x * 1e-3 + i;
+  const double w = 123456789.0, pinv = 1.0 / 281474976768001.0, p = 281474976768001.0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const double h = v[i] * w;
+      const double l = __builtin_fma(v[i], w, -h);
+      const double q = __builtin_rint(h * pinv);
+      const double r = __builtin_fma(-q, p, h);
+      v[i] = r + l;
+    }
+  }
+  double s = 0; for (int i = 0; i < CH; ++i) s += v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int CH> static void chain_probe(double* d, int blocks) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  const int iters = 4096;
+  for (int r = 0; r < 200; ++r) k_chain<CH><<<blocks, 512>>>(d, iters);   // settle the clock
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int r = 0; r < 20; ++r) k_chain<CH><<<blocks, 512>>>(d, iters);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double winst = (double)blocks * 8 / 1024 * iters * CH * 6 * 20;
+  printf("mulmod chains: %d waves/SIMD, %d independent chains/thread: %.2f ns per wave-instr per SIMD\n", blocks * 8 / 1024, CH, ms * 1e6 / winst);
+}
+
 static void clock_probe(double* d) {
   const int blocks = 512, iters = 1 << 16;
   unsigned long long* st; hipMalloc(&st, blocks * 2 * sizeof(unsigned long long));
@@ -118,6 +150,8 @@ int main() {
   run<20>("v_cndmask_b32 (asm)", d, 1, f);
   run<7>("add i64 (C: add_co+addc)", d, 2, f);
   clock_probe(d);
+  chain_probe<1>(d, 256); chain_probe<2>(d, 256); chain_probe<4>(d, 256); chain_probe<8>(d, 256);
+  chain_probe<1>(d, 512); chain_probe<2>(d, 512); chain_probe<4>(d, 512); chain_probe<8>(d, 512);
   hipFree(d);
   return 0;
 }
