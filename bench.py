@@ -78,7 +78,8 @@ def pmc_traffic_per_launch(kernel_prefix):
     for k, v in json.load(open(path)).items():
         if kernel_prefix in k and isinstance(v, dict) and "FETCH_SIZE_per_launch" in v and "WRITE_SIZE_per_launch" in v:
             tot += v["launches"] * (2.0 * v["FETCH_SIZE_per_launch"] + v["WRITE_SIZE_per_launch"]) * 1024.0
-            n += v["launches"]
+            if "_norm" not in k:      # the normalisation pass of a limb-parallel op belongs to the same launch of the class
+                n += v["launches"]
     return tot / n if n else None
 
 

@@ -1,5 +1,5 @@
 import csv, glob, collections, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 agg = collections.defaultdict(list)
 for r in rows:
