@@ -6,6 +6,52 @@
 #include <vector>
 using namespace fk;
 
+// exchange with un-merged ds_read_b64 (2 LDS cycles each; the compiler's ds_read2_b64 takes 8 for two)
+__device__ __forceinline__ double lds_read64(const double* p) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return v;
+}
+template <int X, int B>
+__device__ __forceinline__ void exchange_inv_asm(double (&x)[B][E], double* data, int tid) {
+#pragma unroll
+    for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X + 1>(tid, k))] = x[b][k];
+    if constexpr (!wave_local<X>()) lds_barrier();
+#pragma unroll
+    for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) x[b][k] = lds_read64(&data[b * LDS_DATA + lay<X>(pat<X>(tid, k))]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <int B, int FULL>
+__global__ __launch_bounds__(T, T / 256) void k_bench_asm(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    double x[B][E];
+    for (int b = 0; b < B; b++)
+        for (int k = 0; k < E; k++) x[b][k] = (double)(tid * 8 + k + b);
+    for (int r = 0; r < reps; r++) {
+        for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+        TwPass t;
+        if (FULL) { inv_twiddles<3>(t, tw, tid); lds_barrier(); for (int b = 0; b < B; b++) inv_pass<3>(x[b], t); inv_twiddles<2>(t, tw, tid); }
+        exchange_inv_asm<2, B>(x, data, tid);
+        if (FULL) { for (int b = 0; b < B; b++) inv_pass<2>(x[b], t); inv_twiddles<1>(t, tw, tid); }
+        exchange_inv_asm<1, B>(x, data, tid);
+        if (FULL) { for (int b = 0; b < B; b++) inv_pass<1>(x[b], t); inv_twiddles<0>(t, tw, tid); }
+        exchange_inv_asm<0, B>(x, data, tid);
+        if (FULL) { for (int b = 0; b < B; b++) inv_pass<0>(x[b], t); }
+        for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+    }
+    double s = 0;
+    for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) s += x[b][k];
+    sink[blockIdx.x * T + tid] = s;
+}
+
 // VARIANT 0: full ntt_inv<B>;  1: no workgroup barriers;  2: no LDS exchanges (butterflies + twiddle reads only);
 //         3: exchanges only (no butterflies)
 template <int B, int VARIANT>
@@ -214,6 +260,8 @@ int main() {
     run<3, 0>("inverse transform, full", tw, sink, 256);
     run<3, 2>("  butterflies + twiddle reads only", tw, sink, 256);
     run<3, 3>("  exchanges only", tw, sink, 256);
+    run_pipe2(k_bench_asm<1, 1>, "full, un-merged ds_read_b64 (x2 = per transform)", tw, sink, 256);
+    run_pipe2(k_bench_asm<1, 0>, "exchanges only, un-merged ds_read_b64 (x2)", tw, sink, 256);
     run_pipe2(k_pipe2, "two transforms, coarse pipeline", tw, sink, 256);
     run_pipe2(k_pipe2g, "two transforms, DS ops spread over VALU", tw, sink, 256);
     hipFree(tw); hipFree(sink);
