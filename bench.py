@@ -226,7 +226,7 @@ def main():
         "metric": f"encrypted RAM read ops/s + write ops/s at 2^{args.log_max_addr} entries; achieved HBM GB/s vs peak",
         "value": ops_per_s, "unit": "RAM ops/s (1 read + 1 write[=rpw+write] per step)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "mode": args.mode, "vs_baseline": None, "dtype": "f64 (exact integers mod 2^48+57345)",
+        "higher_is_better": True, "scaling": "weak", "mode": args.mode, "vs_baseline": None, "dtype": "f64", "arithmetic": "exact integers mod 2^48+57345 carried in FP64 (error-free products); int32 limbs in HBM",
         "data": "synthetic",
         "config": {"workload": f"Ram::read + Ram::read_prepare_write + Ram::write, MAX_ADDR=2^{args.log_max_addr}, "
                                f"WORDSIZE={ws}, N=4096, base2k=17, rank=1 (BASELINE.json configs[2]+[3])",
