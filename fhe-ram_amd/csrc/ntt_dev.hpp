@@ -98,10 +98,10 @@ __device__ __forceinline__ void lds_barrier() {
 // B polynomials are transformed together: one LDS exchange moves all of them, and the B
 // independent butterfly streams give the FP64 pipe more ILP.
 // Hazard bookkeeping: positions of pattern 0 (lay<0>(tid + T*k)) are private to a thread.  The only
-// accesses that read what another WAVE wrote are (a) the pattern-1 side of exchange 0 and (b) the
-// automorphism gather in the key-switch kernel; a barrier separates each of them from the writes
-// before it, and a barrier at the first LDS write of every transform separates them from the
-// writes after it.
+// accesses that read what another WAVE wrote are (a) the far side of exchange 0 and (b) the
+// staged-limb gathers in the key-switch kernel; a barrier separates each of them from the writes
+// before it, and a barrier separates them from the writes after it (forward: right after the reads
+// of exchange 0; inverse: at the first LDS write of the next transform).
 template <int X, int B>
 __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, int tid) {
     if constexpr (!wave_local<X>()) lds_barrier();   // cross-wave readers of the previous transform are done
@@ -114,6 +114,9 @@ __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, in
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) x[b][k] = data[b * LDS_DATA + lay<X>(pat<X + 1>(tid, k))];
+    // these reads cross waves, and the next exchange of the forward transform is wave local: it writes
+    // this wave's region without a barrier of its own, so every wave's reads must have landed first
+    if constexpr (!wave_local<X>() && wave_local<X + 1>()) lds_barrier();
 }
 template <int X, int B>
 __device__ __forceinline__ void exchange_inv(double (&x)[B][E], double* data, int tid) {
