@@ -183,3 +183,41 @@ def test_cpp_host_mirror_runs_device_setup_flow(tmp_path):
                            "-L" + libdir, "-lfheram", "-Wl,-rpath," + libdir])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "device-side setup + read + decrypt: ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("max_addr,ws,decomp", [(2, 1, (3, 3, 3, 3)), (1000, 1, (3, 3, 3, 3)), (5000, 3, (3, 3, 3, 3)), (1 << 13, 8, (3, 3, 3, 3)),
+                                                (4097, 2, (3, 3, 3, 3)), (1 << 14, 2, (4, 4, 4)), (3 << 12, 1, (2, 2, 2, 2, 2, 2)), (1 << 13, 1, (6, 6)),
+                                                (1 << 13, 1, (12,)), (5000, 2, (5, 4, 3))])
+def test_odd_shapes_flow_and_oracle_agreement(po, max_addr, ws, decomp):
+    """RAM sizes that are not powers of two (ragged last row, digit plans with a short last digit), below N, and
+    word sizes other than 4 (ram.rs:72-87 takes any word_size / max_addr): device setup, the example's assertions,
+    other digit plans (DECOMP_N, parameters.rs:18,168), and bit-exact agreement of read / read_prepare_write /
+    write with the oracle run on the same state."""
+    pkg = load_package()
+    o = po.Oracle(po.OParams(max_addr=max_addr, word_size=ws, decomp_n=decomp))
+    p = o.p
+    sk = o.secret_gen(3)
+    ram = pkg.Ram.new_from_ram_params(ws, list(decomp), max_addr)
+    dsk = pkg.GLWESecret(ram, sk)
+    keys = pkg.EvaluationKeysPrepared.encrypt_sk(ram, dsk, o.source(1), o.source(2), keep_std=True)
+    rng = np.random.default_rng(max_addr + ws)
+    data = rng.integers(0, 256, size=max_addr * ws, dtype=np.uint8)
+    ram.encrypt_sk(data, dsk, o.source(3), o.source(4))
+    okeys = o.keys_prepare({"gal_els": keys.gal_els, "atk_glwe": np.stack(keys.atk_glwe), "atk_ggsw_inv": keys.atk_ggsw_inv, "tsk": keys.tsk_ggsw_inv})
+    oram = o.ram_new()
+    oram.load(ram.store_encrypted())
+    for idx in sorted({0, max_addr - 1, int(rng.integers(0, max_addr))}):
+        addr = pkg.Address.encrypt_sk(ram, idx, dsk, o.source(5 + idx), o.source(6 + idx))
+        oaddr = o.address_new(np.stack(addr.digits))
+        wants = [pkg.cast_u8_to_signed(int(data[i + ws * idx]), p.k_glwe_pt) for i in range(ws)]
+        got = ram.read(addr, keys)
+        assert np.array_equal(got, oram.read(oaddr, okeys))
+        for (v, noise), want in zip(ram.decrypt_coeff(dsk, got, wants), wants):
+            assert v == want and noise < -(p.k_glwe_pt + 1.0), (idx, v, want, noise)
+        assert np.array_equal(ram.read_prepare_write(addr, keys), oram.read_prepare_write(oaddr, okeys))
+        value = rng.integers(0, 256, size=ws, dtype=np.uint8)
+        w = ram.encrypt_word(dsk, value, o.source(7), o.source(8))
+        ram.write(w, addr, keys)
+        oram.write(w, oaddr, okeys)
+        data[ws * idx:ws * idx + ws] = value
+        assert np.array_equal(ram.store_encrypted(), oram.store())
