@@ -232,13 +232,18 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
 #pragma unroll
         for (int k = 0; k < E; k++) acc[0][k] = 0.0;
         ep_mac<SA, SG>(acc[0], x0, x1, g, ggsw, j, co, -1, tid);
-        ntt_inv<1>(acc, tw, data, tid);
+        ntt_inv<1, false>(acc, tw, data, tid);   // the only inverse transform of this workgroup
         double* bp = big + big_ct() + (long)(co * SG + j) * N;
 #pragma unroll
         for (int k = 0; k < E; k++) bp[tid + T * k] = acc[0][k];
         return;
     }
 
+    // Consecutive inverse transforms alternate between two exchange buffers: the cross-wave reads of one
+    // are then always fenced from the next writes into the same buffer by the exchange-0 barrier of the
+    // transform in between, and no barrier is needed at the start of a transform.
+    constexpr bool DB = (2 * BI <= BMAX);
+    int it = 0;
 #pragma unroll 1
     for (int c = 0; c < NCO; c++) {
         const int co = co0 + c;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
                 if (b > 0) ep_fetch0<SA, SG>(g, ggsw, j - b, co, tid);
                 ep_mac<SA, SG>(acc[b], x0, x1, g, ggsw, j - b, co, j - b - 1, tid);
             }
-            ntt_inv<BI>(acc, tw, data, tid);
+            ntt_inv<BI, !DB>(acc, tw, data + (DB ? (it++ & 1) * BI * LDS_DATA : 0), tid);
             if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid);   // overlaps the normalisation step
 #pragma unroll
             for (int b = 0; b < BI; b++) emit(acc[b], j - b);
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
 #pragma unroll
             for (int k = 0; k < E; k++) acc[0][k] = 0.0;
             ep_mac<SA, SG>(acc[0], x0, x1, g, ggsw, 0, co, -1, tid);
-            ntt_inv<1>(acc, tw, data, tid);
+            ntt_inv<1, !DB>(acc, tw, data + (DB ? (it++ & 1) * BI * LDS_DATA : 0), tid);
             emit(acc[0], 0);
         }
     }
@@ -388,9 +393,13 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     // (KBI at a time) leave alone.
     constexpr int KBI = (SX <= 3) ? BI : 1;
     constexpr int WPC = (SX + 2) / 3;   // packed words per coefficient
-    static_assert((size_t)WPC * N * 8 <= (size_t)(BMAX - KBI) * LDS_DATA * sizeof(double), "body staging does not fit");
+    // double-buffered inverse transforms (see k_ext_product) when the body staging leaves two buffer sets free
+    constexpr bool DB = ((size_t)WPC * N * 8 <= (size_t)(BMAX - 2 * KBI) * LDS_DATA * sizeof(double));
+    constexpr int NBUF = DB ? 2 * KBI : KBI;
+    static_assert((size_t)WPC * N * 8 <= (size_t)(BMAX - NBUF) * LDS_DATA * sizeof(double), "body staging does not fit");
     int* mstage = reinterpret_cast<int*>(data);
-    unsigned long long* bstage = reinterpret_cast<unsigned long long*>(data + KBI * LDS_DATA);
+    unsigned long long* bstage = reinterpret_cast<unsigned long long*>(data + NBUF * LDS_DATA);
+    int it = 0;
     auto stage_body = [&](const int (&v)[SX], int i) {
 #pragma unroll
         for (int w = 0; w < WPC; w++) {
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             fetch(j);
             double acc[1][E];
             mac(acc[0], -1);
-            ntt_inv<1>(acc, tw, data, tid);
+            ntt_inv<1, false>(acc, tw, data, tid);   // the only inverse transform of this workgroup
             add_body(acc[0], j);
             double* bgp = ka.big + big_ct() + (long)(co * SK + j) * N;
 #pragma unroll
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
                 mac(acc[b], j - b - 1);
             }
             STAMP(9 + 4 * (SK - 1 - j));
-            ntt_inv<KBI>(acc, tw, data, tid);
+            ntt_inv<KBI, !DB>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
             if (j - KBI >= 0) fetch(j - KBI);   // next limb's operands: their latency overlaps the post-step
             STAMP(10 + 4 * (SK - 1 - j));
 #pragma unroll
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
         if constexpr (REM == 1) {
             double acc[1][E];
             mac(acc[0], -1);
-            ntt_inv<1>(acc, tw, data, tid);
+            ntt_inv<1, !DB>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
             add_body(acc[0], 0);
             emit(acc[0], 0);
         }
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(T, T / 256) void k_encrypt_sk(int32_t* __restrict__
         for (int k = 0; k < E; k++) { x[0][k] = (double)mi[k]; acc[0][k] = 0.0; }
         ntt_fwd<1>(x, tw, data, tid);
         mac_regs(acc[0], x[0], sh);
-        ntt_inv<1>(acc, tw, data, tid);
+        ntt_inv<1, false>(acc, tw, data, tid);   // follows a forward transform, whose cross-wave reads are fenced
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const double v = (DEC ? (double)bi[k] + acc[0][k] : (double)bi[k] - acc[0][k]) + carry[k];

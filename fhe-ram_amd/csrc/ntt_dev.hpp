@@ -266,7 +266,11 @@ __device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, dou
 }
 // Inverse negacyclic NTT without the 1/N factor.  in: x[b][k] at position E*tid + k, |x| < 16p.
 // out: x[b][k] = N * coefficient(tid + T*k) mod p, centred in [-p/2, p/2].
-template <int B>
+// FENCE: barrier before the first LDS write.  It is needed when other waves may still be reading this
+// buffer across waves (the far side of exchange 0 of the previous inverse transform in the SAME
+// buffer); callers that alternate between two buffers, or whose previous transform was a forward one
+// (its cross-wave reads are fenced inside exchange_fwd), pass false.
+template <int B, bool FENCE = true>
 __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, double* data, int tid) {
 #pragma unroll
     for (int b = 0; b < B; b++)
@@ -274,7 +278,7 @@ __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, dou
         for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
     TwPass t;
     inv_twiddles<NPASS - 1>(t, tw, tid);
-    lds_barrier();   // first LDS write of this transform: earlier cross-wave readers are done
+    if constexpr (FENCE) lds_barrier();   // first LDS write of this transform: earlier cross-wave readers are done
     inv_rec<NPASS - 1, B>(x, t, tw, data, tid);
 #pragma unroll
     for (int b = 0; b < B; b++)
