@@ -52,6 +52,53 @@ __global__ __launch_bounds__(T, T / 256) void k_bench_asm(const double* __restri
     sink[blockIdx.x * T + tid] = s;
 }
 
+// passes 0 and 1 take their (workgroup- / wave-uniform) twiddles from scalar registers, loaded once
+template <int Q>
+__device__ __forceinline__ void inv_twiddles_uniform(TwPass& t, const double* __restrict__ tw_g, int wave) {
+    constexpr int HQ = 1 << (LOGE * Q);
+    const int hm = HQ - 1 - (Q == 0 ? 0 : wave);
+#pragma unroll
+    for (int u = LOGE - 1; u >= 0; u--)
+#pragma unroll
+        for (int j = 0; j < (1 << u); j++) t.w[(1 << u) - 1 + j] = tw_g[(HQ << u) + ((1 << u) - 1 - j) * HQ + hm];
+}
+template <int B>
+__global__ __launch_bounds__(T, T / 256) void k_bench_sgpr(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TwPass u0, u1;
+    inv_twiddles_uniform<0>(u0, tw_g, wave);
+    inv_twiddles_uniform<1>(u1, tw_g, wave);
+    double x[B][E];
+    for (int b = 0; b < B; b++)
+        for (int k = 0; k < E; k++) x[b][k] = (double)(tid * 8 + k + b);
+    for (int r = 0; r < reps; r++) {
+        for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+        TwPass t;
+        inv_twiddles<3>(t, tw, tid);
+        double* buf = data + (r & 1) * LDS_DATA;
+        for (int b = 0; b < B; b++) inv_pass<3>(x[b], t);
+        for (int b = 0; b < B; b++) { x[b][0] = reduce(x[b][0]); x[b][1] = reduce(x[b][1]); }
+        inv_twiddles<2>(t, tw, tid);
+        exchange_inv<2, B>(x, buf, tid);
+        for (int b = 0; b < B; b++) inv_pass<2>(x[b], t);
+        for (int b = 0; b < B; b++) { x[b][0] = reduce(x[b][0]); x[b][1] = reduce(x[b][1]); }
+        exchange_inv<1, B>(x, buf, tid);
+        for (int b = 0; b < B; b++) inv_pass<1>(x[b], u1);
+        for (int b = 0; b < B; b++) { x[b][0] = reduce(x[b][0]); x[b][1] = reduce(x[b][1]); }
+        exchange_inv<0, B>(x, buf, tid);
+        for (int b = 0; b < B; b++) inv_pass<0>(x[b], u0);
+        for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+    }
+    double s = 0;
+    for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) s += x[b][k];
+    sink[blockIdx.x * T + tid] = s;
+}
+
 // VARIANT 0: full ntt_inv<B>;  1: no workgroup barriers;  2: no LDS exchanges (butterflies + twiddle reads only);
 //         3: exchanges only (no butterflies)
 template <int B, int VARIANT>
@@ -260,6 +307,7 @@ int main() {
     run<3, 0>("inverse transform, full", tw, sink, 256);
     run<3, 2>("  butterflies + twiddle reads only", tw, sink, 256);
     run<3, 3>("  exchanges only", tw, sink, 256);
+    run_pipe2(k_bench_sgpr<1>, "double buffered + scalar twiddles in passes 0,1 (x2)", tw, sink, 256);
     run_pipe2(k_bench_asm<1, 1>, "full, un-merged ds_read_b64 (x2 = per transform)", tw, sink, 256);
     run_pipe2(k_bench_asm<1, 0>, "exchanges only, un-merged ds_read_b64 (x2)", tw, sink, 256);
     run_pipe2(k_pipe2, "two transforms, coarse pipeline", tw, sink, 256);
