@@ -1,0 +1,219 @@
+// Private to the C-ABI library (one translation unit, fheram.hip): context / address / secret objects,
+// error and profiling helpers, the int64 <-> int32 layout conversion at the boundary.
+#pragma once
+#include "../../include/fheram.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace fk;
+
+namespace {
+
+typedef unsigned __int128 u128;
+thread_local std::string g_create_err;
+
+uint64_t mulmod_u(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % P_U64); }
+uint64_t powmod_u(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    while (e) { if (e & 1) r = mulmod_u(r, a); a = mulmod_u(a, a); e >>= 1; }
+    return r;
+}
+double centred(uint64_t v) { return v > P_U64 / 2 ? -(double)(P_U64 - v) : (double)v; }
+unsigned brv(unsigned x, int bits) { unsigned r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+
+// Twiddle table in the LDS layout of ntt_dev.hpp: W[2^s + J] (W[i] = psi^bitrev12(i)) is stored
+// at 2^s + j*E^Q + hi with s = LOGE*Q + u, J = hi*2^u + j.
+std::vector<double> make_twiddles() {
+    std::vector<double> tw(N, 0.0);
+    for (int s = 0; s < LOGN; s++) {
+        const int Q = s / LOGE, u = s % LOGE, HQ = 1 << (LOGE * Q);
+        for (int J = 0; J < (1 << s); J++) {
+            const int hi = J >> u, j = J & ((1 << u) - 1);
+            const uint64_t w = powmod_u(PSI_8192, brv((unsigned)((1 << s) + J), LOGN));
+            tw[(1 << s) + j * HQ + hi] = centred(w);
+        }
+    }
+    return tw;
+}
+
+struct ProfCls {
+    uint64_t launches = 0, blocks = 0;
+    double ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace
+
+struct fheram_ctx {
+    fheram_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;    // main stream: every op is ordered on it
+    hipStream_t stream2 = nullptr;   // side stream for work that is independent inside one op (write path)
+    hipStream_t cur = nullptr;       // stream the launchers currently enqueue on
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // derived
+    int ws = 0, n2 = 0, n_digits = 0;
+    size_t rows = 0;        // GLWE rows per sub-RAM held by THIS context (all of them unless sharded)
+    size_t rows_glob = 0;   // rows per sub-RAM of the whole RAM
+    int shard = 0, n_shards = 1;   // row sharding: this context owns rows r = shard (mod n_shards)
+    std::vector<std::vector<int>> base2d;
+    static constexpr int S_CT = 3, S_ADDR = 4, S_EVK = 4, S_INV = 5, DNUM_CT = 3, DNUM_GGSW = 4;
+    static constexpr size_t GLWE = (size_t)S_CT * 2 * N;                   // elements of a ct
+    static constexpr size_t GLWE4 = (size_t)S_ADDR * 2 * N;                // one GGSW row ct
+    static constexpr size_t GGSW = (size_t)DNUM_CT * 2 * GLWE4;            // elements of a GGSW
+    static constexpr size_t ATK = (size_t)DNUM_CT * S_EVK * 2 * N;         // trace key
+    static constexpr size_t EVK5 = (size_t)DNUM_GGSW * S_INV * 2 * N;      // inverse / tensor key
+    // device
+    double* d_tw = nullptr;
+    double ninv = 0.0;
+    double* d_atk = nullptr;       // [log_n] prepared trace keys
+    double* d_atk_inv = nullptr;
+    double* d_tsk = nullptr;
+    int64_t gal[LOGN];
+    bool keys_loaded = false;
+    int32_t* d_data = nullptr;     // [ws][rows] GLWE
+    int32_t* d_tree = nullptr;     // [ws] GLWE (tree[0][0])
+    int32_t* d_scrA = nullptr;     // [ws][rows]  ping-pong arenas: every fused kernel is out of place
+    int32_t* d_scrB = nullptr;     // [ws][rows]
+    int32_t* d_scrC = nullptr;     // [ws][rows]
+    int32_t* d_scrD = nullptr;     // [ws][rows]
+    int32_t* d_res = nullptr;      // [ws]
+    int32_t* d_tmp = nullptr;      // [ws]
+    int32_t* d_tmp2 = nullptr;     // [ws]
+    int32_t* d_w = nullptr;        // [ws]
+    double* d_big = nullptr;       // [LIMB_SPLIT_MAX ciphertexts] un-normalised limbs of the limb-parallel path
+    double* d_big2 = nullptr;      // same, for launches on the side stream
+    int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel path
+    int use_graph = 0;             // FHERAM_GRAPH=1: replay each op's launch sequence from a hipGraph (per address)
+    int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo
+    int32_t* d_gat[3] = {nullptr, nullptr, nullptr};   // [n_shards][ws] gathered partials + ping-pong (root)
+    int nco = 0;                   // output columns per workgroup: 1 = split by column (2 workgroups per
+                                   // ciphertext), 2 = one workgroup, 0 = choose per launch from the batch size
+    int cus = 256;
+    double* d_prep = nullptr;      // [max digits per coordinate] prepared GGSW
+    double* d_prep2 = nullptr;     // second set (inverse coordinate 0, prepared on the side stream)
+    int32_t* d_ggsw_tmp = nullptr; // [max digits per coordinate] std GGSW (inversion result)
+    int32_t* d_ggsw_tmp2 = nullptr;
+    int max_digits = 0;
+    bool initialized = false, state = false, words_staged = false;
+    std::vector<int32_t> h_i32;    // host staging
+    // profiling
+    bool profile = false;
+    std::map<std::string, ProfCls> prof;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::string err;
+};
+
+struct fheram_addr {
+    fheram_ctx* ctx;   // owner (identity check only after creation)
+    int32_t* d_ggsw;   // [n_digits] std-form GGSW, int32
+    int n_digits;
+    int device;
+    hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // captured launch sequences: read, read_prepare_write, write
+};
+
+struct fheram_secret {
+    fheram_ctx* ctx;
+    int device;
+    std::vector<int32_t> sk;   // N coefficients in {-1, 0, 1}
+    double* d_hat;             // prepared (transform domain, 1/N folded in)
+};
+
+namespace {
+
+int fail(fheram_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), FHERAM_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+GlweRef ref(int32_t* p, long sy, long sx) { return GlweRef{p, sy, sx}; }
+
+hipEvent_t get_event(fheram_ctx* c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    fheram_ctx* c; ProfCls* cls = nullptr; hipEvent_t a = nullptr;
+    ProfScope(fheram_ctx* c_, const char* name, uint64_t blocks) : c(c_) {
+        if (!c->profile) return;
+        cls = &c->prof[name];
+        cls->launches++; cls->blocks += blocks;
+        a = get_event(c);
+        hipEventRecord(a, c->cur);
+    }
+    ~ProfScope() {
+        if (!cls) return;
+        hipEvent_t b = get_event(c);
+        hipEventRecord(b, c->cur);
+        cls->pending.emplace_back(a, b);
+    }
+};
+void prof_collect(fheram_ctx* c) {
+    for (auto& kv : c->prof) {
+        for (auto& pr : kv.second.pending) {
+            hipEventSynchronize(pr.second);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            kv.second.ms += ms;
+            c->ev_pool.push_back(pr.first); c->ev_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+int ilog2_ceil(size_t x) { int k = 0; while (((size_t)1 << k) < x) k++; return k; }
+int galois_mod(int64_t g) { const int64_t m = 2 * N; return (int)(((g % m) + m) % m); }
+int galois_inv_mod(int g) {   // g odd; g^(N-1) = g^-1 mod 2N
+    int64_t r = 1, b = g, e = N - 1, m = 2 * N;
+    while (e) { if (e & 1) r = r * b % m; b = b * b % m; e >>= 1; }
+    return (int)r;
+}
+int64_t galois_element(int i) {   // GLWE::trace_galois_elements (keys.rs:39,158)
+    if (i == 0) return -1;
+    int64_t g = 5, e = (int64_t)1 << (i - 1), r = 1, m = 2 * N;
+    while (e) { if (e & 1) r = r * g % m; g = g * g % m; e >>= 1; }
+    return r;
+}
+
+// ---- narrowing / widening between the int64 ABI layout and the int32 device layout ---------
+bool narrow(const int64_t* src, int32_t* dst, size_t n) {
+    int64_t bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int64_t v = src[i];
+        bad |= (v > 65536) | (v < -65536);
+        dst[i] = (int32_t)v;
+    }
+    return bad == 0;
+}
+void widen(const int32_t* src, int64_t* dst, size_t n) { for (size_t i = 0; i < n; i++) dst[i] = src[i]; }
+
+int upload_i64(fheram_ctx* c, int32_t* dst, const int64_t* src, size_t n) {
+    c->h_i32.resize(n);
+    if (!narrow(src, c->h_i32.data(), n)) return fail(c, FHERAM_ERR_RANGE, "limb out of the normalised range [-2^16, 2^16]");
+    HIPCHK(c, hipMemcpyAsync(dst, c->h_i32.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FHERAM_OK;
+}
+int download_i64(fheram_ctx* c, int64_t* dst, const int32_t* src, size_t n) {
+    c->h_i32.resize(n);
+    HIPCHK(c, hipMemcpyAsync(c->h_i32.data(), src, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    widen(c->h_i32.data(), dst, n);
+    return FHERAM_OK;
+}
+
+}  // namespace

@@ -1,0 +1,160 @@
+// Private to fheram.hip: kernel launchers (choice between the fused / column-split / limb-parallel
+// decompositions), dependent chains, the packing tree, coordinate preparation.
+#pragma once
+#include "ctx.hpp"
+
+namespace {
+
+// ---- kernel launchers ---------------------------------------------------------------------
+constexpr int LIMB_SPLIT_MAX = 64;   // ciphertexts per launch the limb-parallel path is used for (at most)
+constexpr int EW_SLICES = 8;   // workgroups per ciphertext of the elementwise kernels (blockIdx.z)
+// One workgroup per ciphertext does the least work (no repeated forward transforms); splitting by
+// output column doubles the number of workgroups, which pays while the batch cannot fill the CUs.
+int pick_nco(const fheram_ctx* c, int gx, int gy) {
+    if (c->nco != 0) return c->nco;
+    return ((long)gx * gy * 2 <= c->cus) ? 1 : 2;
+}
+// gal != 0: automorphism key of Galois element gal, prepared as NTT(phi_gal(K)) (see k_prepare)
+void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly, int64_t gal = 0) {
+    ProfScope ps(c, "prepare", npoly);
+    const int ginv = gal == 0 ? 0 : galois_inv_mod(galois_mod(gal));
+    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->cur, in, out, c->d_tw, c->ninv, ginv);
+}
+// res = a (x) ggsw over a (gx, gy) grid of ciphertexts; res must not alias a
+// Limb-parallel path: 2*SK workgroups per ciphertext + a normalisation pass, chosen while even the
+// column split leaves most CUs idle.
+double* big_of(const fheram_ctx* c) { return c->cur == c->stream2 ? c->d_big2 : c->d_big; }
+bool use_limb_split(const fheram_ctx* c, int gx, int gy, int sk) {
+    return c->limb_split && (long)gx * gy <= LIMB_SPLIT_MAX && (long)gx * gy * 2 * sk <= c->cus;
+}
+void launch_ep(fheram_ctx* c, GlweRef a, GlweRef res, const double* ggsw, int gx, int gy) {
+    if (gx <= 0 || gy <= 0) return;
+    ProfScope ps(c, "ext_product", (uint64_t)gx * gy);
+    if (use_limb_split(c, gx, gy, 4)) {
+        hipLaunchKernelGGL((k_ext_product<3, 4, 1, 1>), dim3(gx, gy, 8), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+        hipLaunchKernelGGL((k_ext_product<3, 4, 1, 2>), dim3(gx, gy, 2), dim3(T), 0, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+        return;
+    }
+    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_ext_product<3, 4, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+    else hipLaunchKernelGGL((k_ext_product<3, 4, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+}
+template <int MODE, int SX, int SK, int SO>
+void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
+    if (gx <= 0 || gy <= 0) return;
+    ProfScope ps(c, "keyswitch", (uint64_t)gx * gy);
+    if (use_limb_split(c, gx, gy, SK)) {
+        KsArgs kb = ka;
+        kb.big = big_of(c);
+        hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1, 1>), dim3(gx, gy, 2 * SK), dim3(T), LDS_BYTES, c->cur, kb);
+        hipLaunchKernelGGL((k_keyswitch_norm<MODE, SX, SK, SO>), dim3(gx, gy, 2 * (N / 256)), dim3(256), 0, c->cur, kb);
+        return;
+    }
+    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);
+    else hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ka);
+}
+void launch_copy(fheram_ctx* c, GlweRef src, GlweRef dst, int gx, int gy) {
+    if (gx <= 0 || gy <= 0) return;
+    ProfScope ps(c, "elementwise", (uint64_t)gx * gy);
+    hipLaunchKernelGGL((k_copy<3>), dim3(gx, gy, EW_SLICES), dim3(256), 0, c->cur, src, dst);
+}
+KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* key, int64_t gal, int t = 0, int rot_mul = 0, int rot_base = 0) {
+    KsArgs ka;
+    ka.a = a; ka.b = b; ka.out = out; ka.key = key; ka.tw = c->d_tw;
+    ka.g = galois_mod(gal); ka.ginv = galois_inv_mod(ka.g); ka.t = t; ka.rot_mul = rot_mul; ka.rot_base = rot_base; ka.big = c->d_big;
+    return ka;
+}
+const double* trace_key(fheram_ctx* c, int i) { return c->d_atk + (size_t)i * fheram_ctx::ATK; }
+bool same(const GlweRef& a, const GlweRef& b) { return a.p == b.p; }
+
+// Runs n dependent out-of-place steps src -> ... -> dst, alternating between dst and tmp so that
+// the last step lands in dst.  step(i, in, out) launches step i.  dst may be src.
+template <typename F>
+void run_chain(fheram_ctx* c, int n, GlweRef src, GlweRef dst, GlweRef tmp, int gx, int gy, F&& step) {
+    if (n <= 0) { if (!same(src, dst)) launch_copy(c, src, dst, gx, gy); return; }
+    if (same(src, dst) && (n % 2 == 1)) {   // the first step would write what it reads: finish in tmp, copy back
+        run_chain(c, n, src, tmp, dst, gx, gy, step);
+        launch_copy(c, tmp, dst, gx, gy);
+        return;
+    }
+    GlweRef cur = src;
+    for (int i = 0; i < n; i++) {
+        GlweRef out = ((n - 1 - i) % 2 == 0) ? dst : tmp;
+        step(i, cur, out);
+        cur = out;
+    }
+}
+// CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): d external products.
+void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, const double* prep, int d, int gx, int gy) {
+    run_chain(c, d, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) { launch_ep(c, in, out, prep + (size_t)i * fheram_ctx::GGSW, gx, gy); });
+}
+// GLWE::trace(start, end): step i = rsh(1) then a += phi_{g_i}(KS(a)).
+// The first step may read its input rotated by X^-(x*rot_mul) (write path, ram.rs:621,629).
+void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start, int end, int gx, int gy, int rot_mul = 0, int rot_base = 0) {
+    run_chain(c, end - start, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) {
+        KsArgs ka = ks_args(c, in, in, out, trace_key(c, start + i), c->gal[start + i], 0, i == 0 ? rot_mul : 0, i == 0 ? rot_base : 0);
+        launch_ks<KS_TRACE, 3, 4, 3>(c, ka, gx, gy);
+    });
+}
+// GLWEPacker (ram.rs:425-448), level-synchronous, over `count` leaves per y at
+// src(x, y); A and B are ping-pong arenas with the same strides (src may be A).
+//   n_alone    : packer levels 0..n_alone-1 in which every leaf is alone (a <- rsh(a); a <- a + phi(a))
+//   first_pair : packer level of the first pairing step; level first_pair + m joins x with x + count/2^(m+1)
+// Whole RAM: n_alone = first_pair = log N - ceil(log2 rows).  Row-sharded RAM: the shards run the
+// levels that stay inside one residue class (same n_alone / first_pair, count = local rows) and the
+// root finishes with n_alone = 0, first_pair = log N - log2(n_shards) over the gathered partials.
+// Returns the arena that holds the packed result at x = 0.
+int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long sy, long sx, size_t count, int gy,
+                     int n_alone, int first_pair) {
+    const int k = ilog2_ceil(count);
+    int32_t* cur = src;
+    auto other = [&](int32_t* x) { return x == A ? B : A; };
+    for (int i = 0; i < n_alone; i++) {
+        int32_t* nxt = other(cur);
+        KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i]);
+        launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)count, gy);
+        cur = nxt;
+    }
+    size_t live = count;
+    for (int m = 0; m < k; m++) {
+        const int i = first_pair + m;
+        const long h = (long)1 << (k - 1 - m);
+        int32_t* nxt = other(cur);
+        const long n_pair = std::max<long>(0, std::min<long>(h, (long)live - h));
+        const long n_alone_here = std::min<long>(h, (long)live) - n_pair;
+        if (n_pair > 0) {
+            KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur + h * sx, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i], N >> (i + 1));
+            launch_ks<KS_PAIR, 3, 4, 3>(c, ka, (int)n_pair, gy);
+        }
+        if (n_alone_here > 0) {
+            KsArgs ka = ks_args(c, ref(cur + n_pair * sx, sy, sx), ref(cur, sy, sx), ref(nxt + n_pair * sx, sy, sx), trace_key(c, i), c->gal[i]);
+            launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)n_alone_here, gy);
+        }
+        live = std::min<size_t>(live, (size_t)h);
+        cur = nxt;
+    }
+    return cur;
+}
+// CoordinatePrepared::prepare (coordinate_prepared.rs:104-116) for coordinate `ci` of addr.
+int coord_first_digit(const fheram_ctx* c, int ci) { int s = 0; for (int i = 0; i < ci; i++) s += (int)c->base2d[i].size(); return s; }
+void coordinate_prepare(fheram_ctx* c, const fheram_addr* addr, int ci) {
+    const int d = (int)c->base2d[ci].size();
+    launch_prepare(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, c->d_prep, d * (int)(fheram_ctx::GGSW / N));
+}
+// CoordinatePrepared::prepare_inv (coordinate_prepared.rs:121-142): GGSW(X^i) -> GGSW(X^-i).
+void ggsw_inverse(fheram_ctx* c, const int32_t* in, int32_t* tmp, int d) {
+    const long g4 = (long)fheram_ctx::GLWE4;
+    int32_t* inp = const_cast<int32_t*>(in);
+    // GGSW::automorphism, column 0 of every row: res[r][0] = phi_-1(KS(in[r][0]))
+    KsArgs ka = ks_args(c, ref(inp, (long)fheram_ctx::GGSW, 2 * g4), ref(inp, 0, 0), ref(tmp, (long)fheram_ctx::GGSW, 2 * g4), c->d_atk_inv, -1);
+    launch_ks<KS_AUTO, 4, 5, 4>(c, ka, fheram_ctx::DNUM_CT, d);
+    // row expansion with the tensor key: res[r][1] = KS_tsk(res[r][0].mask) + (0, res[r][0].body)
+    KsArgs kt = ks_args(c, ref(tmp, (long)fheram_ctx::GGSW, 2 * g4), ref(tmp, 0, 0), ref(tmp + g4, (long)fheram_ctx::GGSW, 2 * g4), c->d_tsk, 1);
+    launch_ks<KS_TENSOR, 4, 5, 4>(c, kt, fheram_ctx::DNUM_CT, d);
+}
+void coordinate_prepare_inv(fheram_ctx* c, const fheram_addr* addr, int ci, int32_t* tmp, double* prep) {
+    const int d = (int)c->base2d[ci].size();
+    ggsw_inverse(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, tmp, d);
+    launch_prepare(c, tmp, prep, d * (int)(fheram_ctx::GGSW / N));
+}
+
+}  // namespace

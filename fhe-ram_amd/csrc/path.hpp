@@ -1,0 +1,173 @@
+// Private to fheram.hip: Ram::read / read_prepare_write / write as launch sequences (reference: src/ram.rs).
+#pragma once
+#include "launch.hpp"
+
+namespace {
+
+// The launch sequence of an op is a pure function of (context, address, op): with FHERAM_GRAPH=1 it is
+// captured once per address into a hipGraph and replayed, instead of being re-enqueued kernel by kernel.
+template <typename F>
+int run_op(fheram_ctx* c, const fheram_addr* addr, int which, F&& enqueue) {
+    if (!c->use_graph || c->profile) return enqueue();
+    fheram_addr* a = const_cast<fheram_addr*>(addr);
+    if (!a->graph[which]) {
+        hipGraph_t g = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue();
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc != FHERAM_OK || e != hipSuccess) {
+            if (g) hipGraphDestroy(g);
+            return rc != FHERAM_OK ? rc : fail(c, FHERAM_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        }
+        const hipError_t e2 = hipGraphInstantiate(&a->graph[which], g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e2 != hipSuccess) { a->graph[which] = nullptr; return fail(c, FHERAM_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+    }
+    HIPCHK(c, hipGraphLaunch(a->graph[which], c->stream));
+    return FHERAM_OK;
+}
+
+int check_common(fheram_ctx* c, const fheram_addr* addr) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    if (!addr || addr->ctx != c) return fail(c, FHERAM_ERR_INVALID_ARG, "address does not belong to this context (layout mismatch, ram.rs:404)");
+    if (!c->initialized) return fail(c, FHERAM_ERR_UNINITIALIZED, "unitialized memory: self.data.len()=0");
+    if (!c->keys_loaded) return fail(c, FHERAM_ERR_KEYS, "evaluation keys not loaded");
+    return FHERAM_OK;
+}
+
+// SubRam::read (ram.rs:382-459) / SubRam::read_prepare_write (ram.rs:461-542) for all sub-RAMs at
+// once, in two stages so that a row-sharded RAM can exchange between them.
+// Stage 1 (every shard): coordinate-0 products on the local rows + the packing levels that stay
+// inside the shard.  Leaves one GLWE per sub-RAM in d_part.
+int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    const int ws = c->ws;
+    const int R = (int)c->rows;
+    GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G);
+    GlweRef part = ref(c->d_part, G, 0);
+    coordinate_prepare(c, addr, 0);                                                   // ram.rs:416-419 / 496-499
+    const int d0 = (int)c->base2d[0].size();
+    if (c->n2 == 1) {
+        GlweRef row0 = ref(c->d_data, sy, 0);
+        if (prepare_write) {
+            ep_chain(c, row0, row0, ref(c->d_scrA, sy, 0), c->d_prep, d0, 1, ws);     // ram.rs:502-504 (rows == 1)
+            launch_copy(c, row0, part, 1, ws);
+        } else {
+            ep_chain(c, row0, part, ref(c->d_tmp, G, 0), c->d_prep, d0, 1, ws);       // ram.rs:451
+        }
+        return FHERAM_OK;
+    }
+    int32_t* leaves;
+    if (prepare_write) {
+        ep_chain(c, data, data, A, c->d_prep, d0, R, ws);                             // ram.rs:502-504
+        leaves = c->d_data;
+    } else {
+        ep_chain(c, data, A, B, c->d_prep, d0, R, ws);                                // ram.rs:429-434
+        leaves = c->d_scrA;
+    }
+    const int L0 = LOGN - ilog2_ceil(c->rows_glob);
+    int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws, L0, L0);   // ram.rs:435-448 / 510-521
+    launch_copy(c, ref(packed, sy, 0), part, 1, ws);
+    return FHERAM_OK;
+}
+// Stage 2 (root / unsharded): remaining packing levels over the shards' partials (`gathered`:
+// [n_shards][ws] GLWEs, or nullptr when the RAM is not sharded and the packed rows are in d_part),
+// coordinate-1 products and the final trace.  Result left in d_res.
+int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t* gathered) {
+    const long G = (long)fheram_ctx::GLWE;
+    const int ws = c->ws;
+    GlweRef res = ref(c->d_res, G, 0), tmp = ref(c->d_tmp, G, 0), tree = ref(c->d_tree, G, 0);
+    GlweRef pk = ref(c->d_part, G, 0);
+    if (c->n2 == 2) {
+        if (gathered) {
+            const int kG = ilog2_ceil((size_t)c->n_shards);
+            int32_t* a0 = c->d_gat[1];   // gathered partials live in d_gat[0]
+            int32_t* a1 = c->d_gat[2];
+            int32_t* packed = pack_levels(c, gathered, a0, a1, G, (long)ws * G, (size_t)c->n_shards, ws, 0, LOGN - kG);
+            pk = ref(packed, G, 0);
+        }
+        coordinate_prepare(c, addr, 1);
+        const int d1 = (int)c->base2d[1].size();
+        if (prepare_write) {
+            launch_copy(c, pk, tree, 1, ws);                                          // ram.rs:525-527
+            ep_chain(c, tree, tree, tmp, c->d_prep, d1, 1, ws);                       // ram.rs:502-504 (i = 1)
+            launch_copy(c, tree, res, 1, ws);                                         // ram.rs:535
+        } else {
+            ep_chain(c, pk, res, tmp, c->d_prep, d1, 1, ws);                          // ram.rs:454
+        }
+    } else {
+        launch_copy(c, pk, res, 1, ws);                                               // ram.rs:452 / 537
+    }
+    trace_steps(c, res, res, tmp, 0, LOGN, 1, ws);                                    // ram.rs:457 / 540
+    return FHERAM_OK;
+}
+int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
+    int rc = read_local(c, addr, prepare_write);
+    if (rc != FHERAM_OK) return rc;
+    rc = read_top(c, addr, prepare_write, nullptr);
+    if (rc == FHERAM_OK && prepare_write) c->state = true;                            // ram.rs:533
+    return rc;
+}
+
+// Ram::write (ram.rs:226-294) in two stages.
+// Stage 1 (root / unsharded): write_first_step on the top of the tree and, for n2 == 2, the inverse
+// coordinate-1 products: leaves the un-rotated ct_lo of every sub-RAM in d_part.
+int write_top(fheram_ctx* c, const fheram_addr* addr) {
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    const int ws = c->ws;
+    GlweRef wref = ref(c->d_w, G, 0), tmp = ref(c->d_tmp, G, 0), tmp2 = ref(c->d_tmp2, G, 0), tree = ref(c->d_tree, G, 0);
+    // write_first_step (ram.rs:544-577): t <- normalize(t - trace(t) + w)
+    GlweRef top = (c->n2 != 1) ? tree : ref(c->d_data, sy, 0);
+    trace_steps(c, top, tmp, tmp2, 0, LOGN, 1, ws);
+    {
+        ProfScope ps(c, "elementwise", ws);
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, top, tmp, wref, top);
+    }
+    if (c->n2 == 2) {
+        coordinate_prepare_inv(c, addr, 1, c->d_ggsw_tmp, c->d_prep);                 // ram.rs:260-271
+        ep_chain(c, tree, tree, tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);     // ram.rs:610
+        launch_copy(c, tree, ref(c->d_part, G, 0), 1, ws);
+        {   // ct_lo ends up rotated `rows` times by X^-1 (ram.rs:629)
+            ProfScope ps(c, "elementwise", ws);
+            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, tree, tmp, -(int)c->rows_glob);
+        }
+        launch_copy(c, tmp, tree, 1, ws);
+    }
+    return FHERAM_OK;
+}
+// Work of a write that does not depend on stage 1: tmp_a = trace(ct_hi) for every local row
+// (ram.rs:616) and the inverse of coordinate 0 (ram.rs:278-289).  It is enqueued on the side stream
+// so that it fills the CUs the latency-bound stage 1 (a chain of word_size-ciphertext launches)
+// leaves idle.
+void write_side_begin(fheram_ctx* c, const fheram_addr* addr) {
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    hipEventRecord(c->ev_fork, c->stream);            // everything before this write (rows after rpw)
+    hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+    c->cur = c->stream2;
+    if (c->n2 == 2) trace_steps(c, ref(c->d_data, sy, G), ref(c->d_scrA, sy, G), ref(c->d_scrC, sy, G), 0, LOGN, (int)c->rows, c->ws);
+    coordinate_prepare_inv(c, addr, 0, c->d_ggsw_tmp2, c->d_prep2);
+    hipEventRecord(c->ev_join, c->stream2);
+    c->cur = c->stream;
+}
+// Stage 2 (every shard): write_mid_step on the local rows given ct_lo (in d_part), then write_last_step.
+int write_rows(fheram_ctx* c, const fheram_addr* addr) {
+    const long G = (long)fheram_ctx::GLWE;
+    const long sy = (long)c->rows * G;
+    const int ws = c->ws, R = (int)c->rows;
+    GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G), D = ref(c->d_scrD, sy, G);
+    if (c->n2 == 2)
+        trace_steps(c, ref(c->d_part, G, 0), B, D, 0, LOGN, R, ws, c->n_shards, c->shard);     // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
+    hipStreamWaitEvent(c->stream, c->ev_join, 0);                                              // side stream: trace(ct_hi), inverse coordinate 0
+    if (c->n2 == 2) {
+        ProfScope ps(c, "elementwise", (uint64_t)R * ws);
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws, EW_SLICES), dim3(256), 0, c->cur, data, A, B, data);   // ram.rs:617,625-626
+    }
+    ep_chain(c, data, data, A, c->d_prep2, (int)c->base2d[0].size(), R, ws);                   // ram.rs:644-646
+    c->state = false;                                                                          // ram.rs:648
+    return FHERAM_OK;
+}
+
+}  // namespace
