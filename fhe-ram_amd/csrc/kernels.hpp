@@ -140,12 +140,16 @@ template <int SA, int SG>
 __device__ __forceinline__ void ep_mac(double (&acc)[E], const double (&x0)[SA][E], const double (&x1)[SA][E], OpRegs (&g)[SA],
                                        const double* __restrict__ ggsw, int j, int co, int jnext, int tid) {
     // g holds the column_in 0 operands of limb j on entry (requested by ep_fetch0 after the previous
-    // inverse transform); the column_in 1 operands are fetched between the two halves of the MAC
+    // inverse transform)
+    // each operand register set is refilled with the column_in 1 operands as soon as its column_in 0 product
+    // has been taken, so the refills are in flight during the remaining products of the first half
 #pragma unroll
-    for (int r = 0; r < SA; r++) mac_regs(acc, x0[r], g[r]);
-#pragma unroll
-    for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r + 1) * SG + j) * 2 + co) * N, tid);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < SA; r++) {
+        mac_regs(acc, x0[r], g[r]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_ops(g[r], ggsw + (long)(((2 * r + 1) * SG + j) * 2 + co) * N, tid);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int r = 0; r < SA; r++) mac_regs(acc, x1[r], g[r]);
     (void)jnext;
