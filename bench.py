@@ -140,7 +140,8 @@ def main():
         if args.all_ranks_device0:
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        kw = {"device_id": torch.device("cuda", local_rank)} if args.dist_backend == "nccl" else {}
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world, **kw)   # nccl == RCCL on ROCm
 
     from _pkg import load_package
     pkg = load_package()
