@@ -350,7 +350,8 @@ int fheram_read_partial(fheram_ctx* c, const fheram_addr* addr, int prepare_writ
     if (!out) return fail(c, FHERAM_ERR_INVALID_ARG, "null output");
     if (c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
     HIPCHK(c, hipSetDevice(c->device));
-    rc = read_local(c, addr, prepare_write != 0);
+    GlweRef packed;
+    rc = read_local(c, addr, prepare_write != 0, &packed, true);
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
     if (prepare_write) c->state = true;
@@ -371,7 +372,7 @@ int fheram_read_finish(fheram_ctx* c, const fheram_addr* addr, int prepare_write
         rc = import_glwes(c, c->d_part, partials, partials_on_device, (size_t)c->ws);
     }
     if (rc != FHERAM_OK) return rc;
-    rc = read_top(c, addr, prepare_write != 0, gathered);
+    rc = read_top(c, addr, prepare_write != 0, gathered, ref(c->d_part, (long)fheram_ctx::GLWE, 0));
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
     return out ? fheram_result_download(c, out) : fheram_sync(c);

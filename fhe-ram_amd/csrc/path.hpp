@@ -38,8 +38,9 @@ int check_common(fheram_ctx* c, const fheram_addr* addr) {
 // SubRam::read (ram.rs:382-459) / SubRam::read_prepare_write (ram.rs:461-542) for all sub-RAMs at
 // once, in two stages so that a row-sharded RAM can exchange between them.
 // Stage 1 (every shard): coordinate-0 products on the local rows + the packing levels that stay
-// inside the shard.  Leaves one GLWE per sub-RAM in d_part.
-int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
+// inside the shard.  The packed GLWE of every sub-RAM is left where the last launch wrote it (*packed_out,
+// indexed by sub-RAM); to_part also copies it into d_part (the buffer a sharded RAM exchanges).
+int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweRef* packed_out, bool to_part) {
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     const int ws = c->ws;
@@ -52,9 +53,11 @@ int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
         GlweRef row0 = ref(c->d_data, sy, 0);
         if (prepare_write) {
             ep_chain(c, row0, row0, ref(c->d_scrA, sy, 0), c->d_prep, d0, 1, ws);     // ram.rs:502-504 (rows == 1)
-            launch_copy(c, row0, part, 1, ws);
+            *packed_out = row0;
+            if (to_part) launch_copy(c, row0, part, 1, ws);
         } else {
             ep_chain(c, row0, part, ref(c->d_tmp, G, 0), c->d_prep, d0, 1, ws);       // ram.rs:451
+            *packed_out = part;
         }
         return FHERAM_OK;
     }
@@ -68,17 +71,19 @@ int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
     }
     const int L0 = LOGN - ilog2_ceil(c->rows_glob);
     int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws, L0, L0);   // ram.rs:435-448 / 510-521
-    launch_copy(c, ref(packed, sy, 0), part, 1, ws);
+    *packed_out = ref(packed, sy, 0);
+    if (to_part) launch_copy(c, *packed_out, part, 1, ws);
     return FHERAM_OK;
 }
 // Stage 2 (root / unsharded): remaining packing levels over the shards' partials (`gathered`:
-// [n_shards][ws] GLWEs, or nullptr when the RAM is not sharded and the packed rows are in d_part),
-// coordinate-1 products and the final trace.  Result left in d_res.
-int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t* gathered) {
+// [n_shards][ws] GLWEs, or nullptr when the RAM is not sharded and the packed rows are at `pk`),
+// coordinate-1 products and the final trace.  Result left in d_res.  Every step is out of place, so
+// nothing has to be copied between them.
+int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t* gathered, GlweRef pk) {
     const long G = (long)fheram_ctx::GLWE;
     const int ws = c->ws;
     GlweRef res = ref(c->d_res, G, 0), tmp = ref(c->d_tmp, G, 0), tree = ref(c->d_tree, G, 0);
-    GlweRef pk = ref(c->d_part, G, 0);
+    GlweRef last = pk;
     if (c->n2 == 2) {
         if (gathered) {
             const int kG = ilog2_ceil((size_t)c->n_shards);
@@ -90,22 +95,21 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
         coordinate_prepare(c, addr, 1);
         const int d1 = (int)c->base2d[1].size();
         if (prepare_write) {
-            launch_copy(c, pk, tree, 1, ws);                                          // ram.rs:525-527
-            ep_chain(c, tree, tree, tmp, c->d_prep, d1, 1, ws);                       // ram.rs:502-504 (i = 1)
-            launch_copy(c, tree, res, 1, ws);                                         // ram.rs:535
+            ep_chain(c, pk, tree, tmp, c->d_prep, d1, 1, ws);                         // ram.rs:525-527 + 502-504 (i = 1): tree[0] <- rotated packed row
+            last = tree;                                                              // ram.rs:535 (res <- tree[0])
         } else {
             ep_chain(c, pk, res, tmp, c->d_prep, d1, 1, ws);                          // ram.rs:454
+            last = res;
         }
-    } else {
-        launch_copy(c, pk, res, 1, ws);                                               // ram.rs:452 / 537
-    }
-    trace_steps(c, res, res, tmp, 0, LOGN, 1, ws);                                    // ram.rs:457 / 540
+    }                                                                                 // n2 == 1: res <- packed row (ram.rs:452 / 537)
+    trace_steps(c, last, res, tmp, 0, LOGN, 1, ws);                                   // ram.rs:457 / 540
     return FHERAM_OK;
 }
 int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
-    int rc = read_local(c, addr, prepare_write);
+    GlweRef packed;
+    int rc = read_local(c, addr, prepare_write, &packed, false);
     if (rc != FHERAM_OK) return rc;
-    rc = read_top(c, addr, prepare_write, nullptr);
+    rc = read_top(c, addr, prepare_write, nullptr, packed);
     if (rc == FHERAM_OK && prepare_write) c->state = true;                            // ram.rs:533
     return rc;
 }
