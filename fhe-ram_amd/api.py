@@ -413,6 +413,9 @@ class Ram:
     def _use_keys(self, keys: EvaluationKeysPrepared):
         if self._keys is keys:
             return
+        if keys.atk_glwe is None:
+            raise FheRamError(5, "these keys were generated on another context's device (EvaluationKeysPrepared.encrypt_sk "
+                                 "without keep_std=True): their std forms are not on the host")
         L = library()
         arr = (I64P * len(keys.atk_glwe))(*[_p(k) for k in keys.atk_glwe])
         self._chk(L.fheram_keys_load(self._h, _p(keys.gal_els), len(keys.gal_els), arr, _p(keys.atk_ggsw_inv),

@@ -127,6 +127,10 @@ def test_setup_argument_errors(env, po):
         ram.glwe_encrypt_sk(dsk, 1, 3, 60, None, 0, o.source(1), o.source(2))
     with pytest.raises(pkg.FheRamError, match=r"base2d.max\(\) > value"):      # address.rs:98
         pkg.Address.encrypt_sk(ram, 1 << 14, dsk, o.source(1), o.source(2))
+    keys = pkg.EvaluationKeysPrepared.encrypt_sk(ram, dsk, o.source(1), o.source(2))
+    other.load_encrypted(np.zeros((4, 1, other.params.glwe_len()), dtype=np.int64))
+    with pytest.raises(pkg.FheRamError, match="another context's device"):         # device-only keys cannot move
+        other.read(pkg.Address.alloc_from_params(other.params), keys)
 
 
 @pytest.mark.parametrize("max_addr", [1 << 14, 1 << 16, 1 << 21, 1 << 24])
