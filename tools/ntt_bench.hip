@@ -99,6 +99,42 @@ __global__ __launch_bounds__(T, T / 256) void k_bench_sgpr(const double* __restr
     sink[blockIdx.x * T + tid] = s;
 }
 
+// all twiddles from global memory (L1/L2) or scalar registers: none in LDS
+template <int B>
+__global__ __launch_bounds__(T, T / 256) void k_bench_gtw(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TwPass u0, u1;
+    inv_twiddles_uniform<0>(u0, tw_g, wave);
+    inv_twiddles_uniform<1>(u1, tw_g, wave);
+    double x[B][E];
+    for (int b = 0; b < B; b++)
+        for (int k = 0; k < E; k++) x[b][k] = (double)(tid * 8 + k + b);
+    for (int r = 0; r < reps; r++) {
+        for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+        TwPass t3, t2;
+        inv_twiddles<3>(t3, tw_g, tid);      // same index arithmetic, global table
+        inv_twiddles<2>(t2, tw_g, tid);
+        double* buf = data + (r & 1) * LDS_DATA;
+        for (int b = 0; b < B; b++) inv_pass<3>(x[b], t3);
+        for (int b = 0; b < B; b++) { x[b][0] = reduce(x[b][0]); x[b][1] = reduce(x[b][1]); }
+        exchange_inv<2, B>(x, buf, tid);
+        for (int b = 0; b < B; b++) inv_pass<2>(x[b], t2);
+        for (int b = 0; b < B; b++) { x[b][0] = reduce(x[b][0]); x[b][1] = reduce(x[b][1]); }
+        exchange_inv<1, B>(x, buf, tid);
+        for (int b = 0; b < B; b++) inv_pass<1>(x[b], u1);
+        for (int b = 0; b < B; b++) { x[b][0] = reduce(x[b][0]); x[b][1] = reduce(x[b][1]); }
+        exchange_inv<0, B>(x, buf, tid);
+        for (int b = 0; b < B; b++) inv_pass<0>(x[b], u0);
+        for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+    }
+    double s = 0;
+    for (int b = 0; b < B; b++) for (int k = 0; k < E; k++) s += x[b][k];
+    sink[blockIdx.x * T + tid] = s;
+}
+
 // VARIANT 0: full ntt_inv<B>;  1: no workgroup barriers;  2: no LDS exchanges (butterflies + twiddle reads only);
 //         3: exchanges only (no butterflies)
 template <int B, int VARIANT>
@@ -307,6 +343,7 @@ int main() {
     run<3, 0>("inverse transform, full", tw, sink, 256);
     run<3, 2>("  butterflies + twiddle reads only", tw, sink, 256);
     run<3, 3>("  exchanges only", tw, sink, 256);
+    run_pipe2(k_bench_gtw<1>, "double buffered, no twiddles in LDS (x2)", tw, sink, 256);
     run_pipe2(k_bench_sgpr<1>, "double buffered + scalar twiddles in passes 0,1 (x2)", tw, sink, 256);
     run_pipe2(k_bench_asm<1, 1>, "full, un-merged ds_read_b64 (x2 = per transform)", tw, sink, 256);
     run_pipe2(k_bench_asm<1, 0>, "exchanges only, un-merged ds_read_b64 (x2)", tw, sink, 256);
