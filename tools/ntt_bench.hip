@@ -135,6 +135,69 @@ __global__ __launch_bounds__(T, T / 256) void k_bench_gtw(const double* __restri
     sink[blockIdx.x * T + tid] = s;
 }
 
+// Split-phase workgroup barrier in LDS (arrive = one ds_add per wave, wait = bounded spin) with independent
+// VALU work (a MAC-sized block: 24 mulmod-accumulates) between the two, against the same work after s_barrier.
+__device__ __forceinline__ void sw_arrive(unsigned* cnt) {
+    if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(size_t)cnt), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void sw_wait(unsigned* cnt, unsigned target) {
+    for (int spin = 0; spin < (1 << 20); spin++) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)cnt) : "memory");
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+template <int SPLIT>
+__global__ __launch_bounds__(T, T / 256) void k_bench_split(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    unsigned* cnt = reinterpret_cast<unsigned*>(data + 2 * LDS_DATA);   // two counters in the third buffer
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    double x[1][E], op[3][E], xh[3][E], acc[E];
+    for (int k = 0; k < E; k++) { x[0][k] = (double)(tid * 8 + k); acc[k] = 0; for (int r = 0; r < 3; r++) { op[r][k] = 1000.0 + r + k + tid; xh[r][k] = 77.0 * r + k + tid; } }
+    for (int r = 0; r < reps; r++) {
+        for (int k = 0; k < E; k++) x[0][k] = reduce(x[0][k]);
+        TwPass t;
+        inv_twiddles<3>(t, tw, tid);
+        double* buf = data + (r & 1) * LDS_DATA;
+        inv_pass<3>(x[0], t); x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
+        inv_twiddles<2>(t, tw, tid);
+        exchange_inv<2, 1>(x, buf, tid);
+        inv_pass<2>(x[0], t); x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
+        inv_twiddles<1>(t, tw, tid);
+        exchange_inv<1, 1>(x, buf, tid);
+        inv_pass<1>(x[0], t); x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
+        inv_twiddles<0>(t, tw, tid);
+        for (int k = 0; k < E; k++) buf[lay<0>(pat<1>(tid, k))] = x[0][k];
+        if (SPLIT) {
+            sw_arrive(&cnt[r & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < E; k++) acc[k] = 0.0;
+            for (int q = 0; q < 3; q++) for (int k = 0; k < E; k++) acc[k] = macmod(acc[k], xh[q][k], op[q][k]);   // the next limb's MAC
+            __builtin_amdgcn_sched_barrier(0);
+            sw_wait(&cnt[r & 1], 8u * (unsigned)(r / 2 + 1));
+        } else {
+            lds_barrier();
+        }
+        for (int k = 0; k < E; k++) x[0][k] = buf[lay<0>(pat<0>(tid, k))];
+        inv_pass<0>(x[0], t);
+        for (int k = 0; k < E; k++) x[0][k] = reduce(x[0][k]);
+        if (!SPLIT) {
+            for (int k = 0; k < E; k++) acc[k] = 0.0;
+            for (int q = 0; q < 3; q++) for (int k = 0; k < E; k++) acc[k] = macmod(acc[k], xh[q][k], op[q][k]);
+        }
+        for (int k = 0; k < E; k++) xh[0][k] += acc[k] * 1e-30;   // keep the MAC alive
+    }
+    double s = 0;
+    for (int k = 0; k < E; k++) s += x[0][k] + xh[0][k];
+    sink[blockIdx.x * T + tid] = s;
+}
+
 // VARIANT 0: full ntt_inv<B>;  1: no workgroup barriers;  2: no LDS exchanges (butterflies + twiddle reads only);
 //         3: exchanges only (no butterflies)
 template <int B, int VARIANT>
@@ -343,6 +406,8 @@ int main() {
     run<3, 0>("inverse transform, full", tw, sink, 256);
     run<3, 2>("  butterflies + twiddle reads only", tw, sink, 256);
     run<3, 3>("  exchanges only", tw, sink, 256);
+    run_pipe2(k_bench_split<0>, "transform + MAC, s_barrier then MAC (x2)", tw, sink, 256);
+    run_pipe2(k_bench_split<1>, "transform + MAC in a split software barrier (x2)", tw, sink, 256);
     run_pipe2(k_bench_gtw<1>, "double buffered, no twiddles in LDS (x2)", tw, sink, 256);
     run_pipe2(k_bench_sgpr<1>, "double buffered + scalar twiddles in passes 0,1 (x2)", tw, sink, 256);
     run_pipe2(k_bench_asm<1, 1>, "full, un-merged ds_read_b64 (x2 = per transform)", tw, sink, 256);
