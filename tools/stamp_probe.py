@@ -25,7 +25,7 @@ def probe(batch, label):
         print(f"  {names[i]:28s} {s[i]-t0:8d} cyc")
     for q in range(4):
         b = 8 + 4 * q
-        print(f"  limb {3-q}: mac {s[b+1]-s[b]:6d}  inv-ntt {s[b+2]-s[b+1]:6d}  body+permute {s[b+3]-s[b+2]:6d}  | start {s[b]-t0}")
+        print(f"  limb {3-q}: mac {s[b+1]-s[b]:6d}  inv-ntt {s[b+2]-s[b+1]:6d}  body add      {s[b+3]-s[b+2]:6d}  | start {s[b]-t0}")
     print(f"  {names[5]:28s} {s[5]-t0:8d} cyc")
 os.environ.setdefault("FHERAM_NCO", "0")
 probe(4, "tail (NCO=1, 8 workgroups)")
