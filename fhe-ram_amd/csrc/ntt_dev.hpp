@@ -1,6 +1,6 @@
 // Negacyclic NTT over Z_p at N = 4096 for gfx950, p = 2^48 + 57345 (p = 1 mod 8192), carried in
-// FP64: CDNA4 has no 64-bit integer multiplier and v_mul_{lo,hi}_u32 is quarter rate, while
-// v_fma_f64 runs at half the fp32 rate, so residues live in doubles and the modular product is
+// FP64: CDNA4 has no 64-bit integer multiplier and v_mul_{lo,hi}_u32 costs 1.75x an FP64 FMA
+// (tools/valu_rate.hip), so residues live in doubles and the modular product is
 // the error-free FMA form  a*b - rint(a*b/p)*p  (5 FP64 ops).  All values are exact integers
 // below 2^53 in magnitude; arithmetic is "lazy" (values drift up to a few p and are pulled back
 // with reduce()).
