@@ -198,6 +198,60 @@ __global__ __launch_bounds__(T, T / 256) void k_bench_split(const double* __rest
     sink[blockIdx.x * T + tid] = s;
 }
 
+// Prototype of the other decomposition: one WAVE per polynomial as a 64 x 64 four-step transform.  Lane b holds
+// the 64 coefficients {64 a + b}: a 64-point transform over a in registers (twiddles wave-uniform: scalar
+// loads), a twist by a per-element factor, one transpose through LDS, a second 64-point transform.  No
+// workgroup barrier.  Arbitrary twiddle values: this measures time, not a usable transform.
+__device__ __forceinline__ void ntt64_regs(double (&x)[64], const double* __restrict__ w) {
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int half = 32 >> s;
+#pragma unroll
+        for (int j = 0; j < (1 << s); j++) {
+            const double tw = w[(1 << s) - 1 + j];      // uniform address: scalar load
+#pragma unroll
+            for (int i = 0; i < half; i++) gs(x[2 * j * half + i], x[2 * j * half + i + half], tw);
+        }
+#pragma unroll
+        for (int k = 0; k < 64; k += 8) x[k] = reduce(x[k]);   // keep magnitudes bounded (cost model only)
+    }
+}
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_wave_ntt(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* buf = lds + wave * (64 * 65);
+    double x[64];
+    for (int a = 0; a < 64; a++) x[a] = (double)(lane + 64 * a);
+    for (int r = 0; r < reps; r++) {
+        ntt64_regs(x, tw_g);
+#pragma unroll
+        for (int a = 0; a < 64; a++) x[a] = mulmod(reduce(x[a]), tw_g[64 + 64 * a + lane]);   // twist, coalesced table read
+#pragma unroll
+        for (int a = 0; a < 64; a++) buf[a * 65 + lane] = x[a];
+#pragma unroll
+        for (int b = 0; b < 64; b++) x[b] = buf[lane * 65 + b];
+        ntt64_regs(x, tw_g);
+    }
+    double s = 0;
+    for (int a = 0; a < 64; a++) s += x[a];
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int WAVES> void run_wave(const double* tw, double* sink, int blocks) {
+    const size_t ldsb = (size_t)WAVES * 64 * 65 * sizeof(double);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_ntt<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    const int reps = 200;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 10; i++) k_wave_ntt<WAVES><<<blocks, 64 * WAVES, ldsb>>>(tw, sink, reps);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < 10; i++) k_wave_ntt<WAVES><<<blocks, 64 * WAVES, ldsb>>>(tw, sink, reps);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    printf("wave-per-polynomial 64x64 prototype, %d waves per CU: %7.3f us per transform per CU (%s)\n", WAVES,
+           ms * 1e3 / (10.0 * reps * WAVES * ((blocks + 255) / 256)), hipGetErrorString(hipGetLastError()));
+}
+
 // VARIANT 0: full ntt_inv<B>;  1: no workgroup barriers;  2: no LDS exchanges (butterflies + twiddle reads only);
 //         3: exchanges only (no butterflies)
 template <int B, int VARIANT>
@@ -387,11 +441,11 @@ template <int B, int VARIANT> void run(const char* name, const double* tw, doubl
 }
 
 int main() {
-    std::vector<double> h(N);
-    for (int i = 0; i < N; i++) h[i] = (double)((i * 2654435761u) % 1000003);   // any values: timing only
+    std::vector<double> h(2 * N);
+    for (int i = 0; i < 2 * N; i++) h[i] = (double)((i * 2654435761u) % 1000003);   // any values: timing only
     double *tw, *sink;
-    hipMalloc(&tw, N * sizeof(double)); hipMalloc(&sink, 512 * T * sizeof(double));
-    hipMemcpy(tw, h.data(), N * sizeof(double), hipMemcpyHostToDevice);
+    hipMalloc(&tw, 2 * N * sizeof(double)); hipMalloc(&sink, 512 * T * sizeof(double));
+    hipMemcpy(tw, h.data(), 2 * N * sizeof(double), hipMemcpyHostToDevice);
     run<1, 0>("inverse transform, full", tw, sink, 256);
     run<1, 1>("  without the workgroup barrier", tw, sink, 256);
     run<1, 2>("  butterflies + twiddle reads only", tw, sink, 256);
@@ -406,6 +460,8 @@ int main() {
     run<3, 0>("inverse transform, full", tw, sink, 256);
     run<3, 2>("  butterflies + twiddle reads only", tw, sink, 256);
     run<3, 3>("  exchanges only", tw, sink, 256);
+    run_wave<4>(tw, sink, 256);
+    run_wave<2>(tw, sink, 256);
     run_pipe2(k_bench_split<0>, "transform + MAC, s_barrier then MAC (x2)", tw, sink, 256);
     run_pipe2(k_bench_split<1>, "transform + MAC in a split software barrier (x2)", tw, sink, 256);
     run_pipe2(k_bench_gtw<1>, "double buffered, no twiddles in LDS (x2)", tw, sink, 256);
