@@ -141,6 +141,36 @@ def test_ntt_matches_schoolbook(po, log_n):
     assert np.array_equal(o.negacyclic_ntt(a, b), po.Oracle.negacyclic_schoolbook(a, b))
 
 
+def test_exact_product_is_what_a_float64_fft_rounds_to(po):
+    """The reference multiplies limb polynomials with an f64 FFT backend and rounds to i64 (examples/fhe-ram.rs:3-7,
+    SURVEY.md A.9).  Emulated with numpy's complex128 FFT (negacyclic through the psi-twist, full-size
+    transform), the rounded result equals the oracle's exact product for random
+    limbs, for the all-extreme-digit worst case, and for a 6-term accumulation as in an external product —
+    i.e. the exact-integer arithmetic restated here is the arithmetic the reference performs whenever its FFT is
+    accurate, which the magnitude bound 6*2^44 << 2^53 guarantees."""
+    n = 4096
+    o = po.Oracle(po.OParams(max_addr=1 << 12))
+    rng = np.random.default_rng(9)
+    twist = np.exp(1j * np.pi * np.arange(n) / n)
+
+    def fft_negacyclic(a, b):
+        fa, fb = np.fft.fft(a * twist), np.fft.fft(b * twist)
+        return np.fft.ifft(fa * fb) / twist
+
+    pairs = [(rng.integers(-(1 << 16), 1 << 16, size=n, dtype=np.int64), rng.integers(-(1 << 16), 1 << 16, size=n, dtype=np.int64))
+             for _ in range(6)]
+    worst = (np.full(n, -(1 << 16), dtype=np.int64), np.full(n, -(1 << 16), dtype=np.int64))
+    for a, b in pairs[:2] + [worst]:
+        c = fft_negacyclic(a.astype(np.float64), b.astype(np.float64))
+        assert np.max(np.abs(c.imag)) < 0.25 and np.max(np.abs(c.real - np.rint(c.real))) < 0.25
+        assert np.array_equal(np.rint(c.real).astype(np.int64), o.negacyclic_ntt(a, b))
+    acc_f = sum(np.fft.fft(a * twist) * np.fft.fft(b * twist) for a, b in pairs)       # accumulate in the transform domain
+    acc = np.fft.ifft(acc_f) / twist
+    want = sum(o.negacyclic_ntt(a, b) for a, b in pairs)
+    assert np.max(np.abs(acc.real - np.rint(acc.real))) < 0.25
+    assert np.array_equal(np.rint(acc.real).astype(np.int64), want)
+
+
 def test_galois_elements(po):  # SURVEY.md A.6
     assert [int(po.lib().fo_galois_element(12, i)) for i in range(12)] == \
         [-1, 5, 25, 625, 5601, 4033, 3969, 7937, 7681, 7169, 6145, 4097]
