@@ -75,6 +75,9 @@ _SYMBOLS = [
     ("fheram_sync", C.c_int, [C.c_void_p]),
     ("fheram_ctx_create_sharded", C.c_int, [C.POINTER(_CParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("fheram_shard_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    ("fheram_stream_signal", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("fheram_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("fheram_write_begin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("fheram_read_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     ("fheram_read_finish", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, I64P]),
     ("fheram_write_root", C.c_int, [C.c_void_p, I64P, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
@@ -577,6 +580,19 @@ class Ram:
         wp = None if w is None else _p(_i64(w))
         self._chk(library().fheram_write_root(self._h, wp, self.params.word_size(), address._device(self), ptr, dev))
         return out
+
+    def write_begin(self, address: Address, keys: EvaluationKeysPrepared):
+        """start the part of a write that does not need ct_lo (overlaps the root's work and the broadcast)"""
+        self._use_keys(keys)
+        self._chk(library().fheram_write_begin(self._h, address._device(self)))
+
+    def stream_signal(self, hip_stream: int):
+        """work enqueued later on `hip_stream` (a hipStream_t as int, 0 = default stream) waits for this context"""
+        self._chk(library().fheram_stream_signal(self._h, C.c_void_p(int(hip_stream))))
+
+    def stream_wait(self, hip_stream: int):
+        """work this context enqueues later waits for everything enqueued on `hip_stream` so far"""
+        self._chk(library().fheram_stream_wait(self._h, C.c_void_p(int(hip_stream))))
 
     def write_shard(self, address: Address, keys: EvaluationKeysPrepared, ct_lo):
         self._use_keys(keys)

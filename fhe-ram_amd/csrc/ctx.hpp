@@ -58,6 +58,8 @@ struct fheram_ctx {
     hipStream_t stream2 = nullptr;   // side stream for work that is independent inside one op (write path)
     hipStream_t cur = nullptr;       // stream the launchers currently enqueue on
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_xout = nullptr, ev_xin = nullptr;   // ordering against a caller's stream (fheram_stream_signal / _wait)
+    bool side_begun = false;                          // write_side_begin has been enqueued for the pending write
     // derived
     int ws = 0, n2 = 0, n_digits = 0;
     size_t rows = 0;        // GLWE rows per sub-RAM held by THIS context (all of them unless sharded)
@@ -103,7 +105,8 @@ struct fheram_ctx {
     int32_t* d_ggsw_tmp2 = nullptr;
     int max_digits = 0;
     bool initialized = false, state = false, words_staged = false;
-    std::vector<int32_t> h_i32;    // host staging
+    int32_t* h_pin[2] = {nullptr, nullptr};   // pinned host staging (hand-over of int64 host buffers)
+    hipEvent_t ev_pin[2] = {nullptr, nullptr};
     // profiling
     bool profile = false;
     std::map<std::string, ProfCls> prof;
@@ -201,18 +204,52 @@ bool narrow(const int64_t* src, int32_t* dst, size_t n) {
 }
 void widen(const int32_t* src, int64_t* dst, size_t n) { for (size_t i = 0; i < n; i++) dst[i] = src[i]; }
 
+// The hand-over goes through two pinned staging buffers of PIN_CHUNK elements: the narrowing / widening
+// of one chunk overlaps the DMA of the other, and the DMA itself runs at the pinned-memory rate (a
+// pageable copy is staged by the runtime a second time).  Both calls return when the data has arrived.
+constexpr size_t PIN_CHUNK = (size_t)1 << 21;   // int32 elements per staging buffer (8 MiB)
+int pin_init(fheram_ctx* c) {
+    if (c->h_pin[0]) return FHERAM_OK;
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(c, hipHostMalloc((void**)&c->h_pin[b], PIN_CHUNK * sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_pin[b], hipEventDisableTiming));
+    }
+    return FHERAM_OK;
+}
 int upload_i64(fheram_ctx* c, int32_t* dst, const int64_t* src, size_t n) {
-    c->h_i32.resize(n);
-    if (!narrow(src, c->h_i32.data(), n)) return fail(c, FHERAM_ERR_RANGE, "limb out of the normalised range [-2^16, 2^16]");
-    HIPCHK(c, hipMemcpyAsync(dst, c->h_i32.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    int rc = pin_init(c);
+    if (rc != FHERAM_OK) return rc;
+    bool ok = true;
+    int k = 0;
+    for (size_t off = 0; off < n && ok; off += PIN_CHUNK, k++) {
+        const int b = k & 1;
+        const size_t m = std::min(PIN_CHUNK, n - off);
+        if (k >= 2) HIPCHK(c, hipEventSynchronize(c->ev_pin[b]));   // the copy that last used this buffer is done
+        ok = narrow(src + off, c->h_pin[b], m);
+        if (!ok) break;
+        HIPCHK(c, hipMemcpyAsync(dst + off, c->h_pin[b], m * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_pin[b], c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!ok) return fail(c, FHERAM_ERR_RANGE, "limb out of the normalised range [-2^16, 2^16]");
     return FHERAM_OK;
 }
 int download_i64(fheram_ctx* c, int64_t* dst, const int32_t* src, size_t n) {
-    c->h_i32.resize(n);
-    HIPCHK(c, hipMemcpyAsync(c->h_i32.data(), src, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    widen(c->h_i32.data(), dst, n);
+    int rc = pin_init(c);
+    if (rc != FHERAM_OK) return rc;
+    const size_t n_chunks = (n + PIN_CHUNK - 1) / PIN_CHUNK;
+    for (size_t k = 0; k <= n_chunks; k++) {
+        if (k < n_chunks) {   // request chunk k
+            const size_t off = k * PIN_CHUNK, m = std::min(PIN_CHUNK, n - off);
+            HIPCHK(c, hipMemcpyAsync(c->h_pin[k & 1], src + off, m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_pin[k & 1], c->stream));
+        }
+        if (k > 0) {          // widen chunk k - 1 while chunk k is in flight
+            const size_t off = (k - 1) * PIN_CHUNK, m = std::min(PIN_CHUNK, n - off);
+            HIPCHK(c, hipEventSynchronize(c->ev_pin[(k - 1) & 1]));
+            widen(c->h_pin[(k - 1) & 1], dst + off, m);
+        }
+    }
     return FHERAM_OK;
 }
 

@@ -85,6 +85,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     c->cur = c->stream;
     CCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    CCHK(hipEventCreateWithFlags(&c->ev_xout, hipEventDisableTiming));
+    CCHK(hipEventCreateWithFlags(&c->ev_xin, hipEventDisableTiming));
     CCHK(hipEventCreate(&c->t0));
     CCHK(hipEventCreate(&c->t1));
     {
@@ -157,10 +159,13 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     prof_collect(c);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_xout) hipEventDestroy(c->ev_xout);
+    if (c->ev_xin) hipEventDestroy(c->ev_xin);
     if (c->stream2) hipStreamDestroy(c->stream2);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
+    for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
     void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -355,9 +360,30 @@ int fheram_read_partial(fheram_ctx* c, const fheram_addr* addr, int prepare_writ
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
     if (prepare_write) c->state = true;
-    rc = export_glwes(c, c->d_part, out, out_on_device, (size_t)c->ws);
-    if (rc == FHERAM_OK && out_on_device) HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller's collective runs on another stream
-    return rc;
+    return export_glwes(c, c->d_part, out, out_on_device, (size_t)c->ws);   // device buffers: asynchronous, see fheram_stream_signal
+}
+int fheram_stream_signal(fheram_ctx* c, void* hip_stream) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->ev_xout, c->stream));
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_xout, 0));
+    return FHERAM_OK;
+}
+int fheram_stream_wait(fheram_ctx* c, void* hip_stream) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->ev_xin, (hipStream_t)hip_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_xin, 0));
+    return FHERAM_OK;
+}
+int fheram_write_begin(fheram_ctx* c, const fheram_addr* addr) {
+    int rc = check_common(c, addr);
+    if (rc != FHERAM_OK) return rc;
+    if (!c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->side_begun) write_side_begin(c, addr);
+    HIPCHK(c, hipGetLastError());
+    return FHERAM_OK;
 }
 int fheram_read_finish(fheram_ctx* c, const fheram_addr* addr, int prepare_write, const void* partials, int partials_on_device, int64_t* out) {
     int rc = check_common(c, addr);
@@ -387,12 +413,11 @@ int fheram_write_root(fheram_ctx* c, const int64_t* w, int n_w, const fheram_add
     HIPCHK(c, hipSetDevice(c->device));
     if (w) { rc = fheram_word_stage(c, w, n_w); if (rc != FHERAM_OK) return rc; }
     else if (!c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
+    if (!c->side_begun) write_side_begin(c, addr);   // the root's own rows: overlaps the latency-bound head below
     rc = write_top(c, addr);
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
-    rc = export_glwes(c, c->d_part, ct_lo_out, out_on_device, (size_t)c->ws);
-    if (rc == FHERAM_OK && out_on_device) HIPCHK(c, hipStreamSynchronize(c->stream));
-    return rc;
+    return export_glwes(c, c->d_part, ct_lo_out, out_on_device, (size_t)c->ws);
 }
 int fheram_write_shard(fheram_ctx* c, const fheram_addr* addr, const void* ct_lo, int on_device) {
     int rc = check_common(c, addr);
@@ -400,9 +425,9 @@ int fheram_write_shard(fheram_ctx* c, const fheram_addr* addr, const void* ct_lo
     if (!ct_lo) return fail(c, FHERAM_ERR_INVALID_ARG, "null ct_lo");
     if (!c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
     HIPCHK(c, hipSetDevice(c->device));
-    write_side_begin(c, addr);   // (a shard could start this before the broadcast arrives; kept here for a simple contract)
+    if (!c->side_begun) write_side_begin(c, addr);   // normally started earlier by fheram_write_begin / fheram_write_root
     rc = import_glwes(c, c->d_part, ct_lo, on_device, (size_t)c->ws);
-    if (rc != FHERAM_OK) return rc;
+    if (rc != FHERAM_OK) { write_side_abort(c); return rc; }
     rc = write_rows(c, addr);
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());

@@ -155,6 +155,14 @@ void write_side_begin(fheram_ctx* c, const fheram_addr* addr) {
     coordinate_prepare_inv(c, addr, 0, c->d_ggsw_tmp2, c->d_prep2);
     hipEventRecord(c->ev_join, c->stream2);
     c->cur = c->stream;
+    c->side_begun = true;
+}
+// Error path of a write whose side-stream work was already enqueued: rejoin the side stream, so that no
+// later operation on the main stream can overtake it.
+void write_side_abort(fheram_ctx* c) {
+    if (!c->side_begun) return;
+    hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    c->side_begun = false;
 }
 // Stage 2 (every shard): write_mid_step on the local rows given ct_lo (in d_part), then write_last_step.
 int write_rows(fheram_ctx* c, const fheram_addr* addr) {
@@ -171,6 +179,7 @@ int write_rows(fheram_ctx* c, const fheram_addr* addr) {
     }
     ep_chain(c, data, data, A, c->d_prep2, (int)c->base2d[0].size(), R, ws);                   // ram.rs:644-646
     c->state = false;                                                                          // ram.rs:648
+    c->side_begun = false;
     return FHERAM_OK;
 }
 

@@ -5,6 +5,21 @@
 // ---- setup side on the device ------------------------------------------
 // Sampling is the caller's: masks and noise arrive as integers; what runs here is the arithmetic.
 namespace {
+// Secret-derived buffers are zeroed before they go back to an allocator: the device ones with a memset that
+// has completed before hipFree, the host ones through a volatile pointer (a plain std::fill right before
+// the delete / return is a dead store the compiler may drop).
+void wipe_free(hipStream_t st, void* d, size_t bytes) {
+    if (!d) return;
+    if (hipMemsetAsync(d, 0, bytes, st) == hipSuccess) hipStreamSynchronize(st);
+    hipFree(d);
+}
+void wipe_host(void* p, size_t bytes) {
+    volatile unsigned char* v = static_cast<volatile unsigned char*>(p);
+    for (size_t i = 0; i < bytes; i++) v[i] = 0;
+}
+}  // namespace
+
+namespace {
 
 constexpr int64_t NOISE_LIM = (int64_t)1 << 30;
 int noise_limb(int k) { return (k + BASE2K - 1) / BASE2K - 1; }
@@ -102,7 +117,7 @@ int fheram_secret_create(fheram_ctx* c, const int64_t* sk, fheram_secret** out) 
     if (e == hipSuccess) e = hipMalloc(&s->d_hat, N * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_in, s->sk.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) { c->cur = c->stream; launch_prepare(c, d_in, s->d_hat, 1); e = hipStreamSynchronize(c->stream); }
-    if (d_in) hipFree(d_in);
+    wipe_free(c->stream, d_in, N * sizeof(int32_t));
     if (e != hipSuccess) { fheram_secret_destroy(s); return fail(c, FHERAM_ERR_DEVICE, std::string("secret prepare: ") + hipGetErrorString(e)); }
     *out = s;
     return FHERAM_OK;
@@ -110,8 +125,8 @@ int fheram_secret_create(fheram_ctx* c, const int64_t* sk, fheram_secret** out) 
 void fheram_secret_destroy(fheram_secret* s) {
     if (!s) return;
     hipSetDevice(s->device);
-    if (s->d_hat) hipFree(s->d_hat);
-    std::fill(s->sk.begin(), s->sk.end(), 0);
+    wipe_free(nullptr, s->d_hat, N * sizeof(double));
+    wipe_host(s->sk.data(), s->sk.size() * sizeof(int32_t));
     delete s;
 }
 
@@ -162,14 +177,14 @@ int fheram_glwe_decrypt(fheram_ctx* c, const fheram_secret* sk, int n_glwe, int 
     if (rc == FHERAM_OK) {
         c->cur = c->stream;
         launch_enc_dyn(c, size, 1, d_ct, sk->d_hat, nullptr, n_glwe);
-        c->h_i32.resize(total);
-        hipError_t e = hipMemcpyAsync(c->h_i32.data(), d_ct, total * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+        std::vector<int32_t> h_i32(total);
+        hipError_t e = hipMemcpyAsync(h_i32.data(), d_ct, total * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(c, FHERAM_ERR_DEVICE, std::string("decrypt: ") + hipGetErrorString(e));
         else
             for (int g = 0; g < n_glwe; g++)
                 for (int j = 0; j < size; j++)
-                    widen(c->h_i32.data() + (size_t)g * glen + (size_t)(j * 2) * N, pt + ((size_t)g * size + j) * N, N);
+                    widen(h_i32.data() + (size_t)g * glen + (size_t)(j * 2) * N, pt + ((size_t)g * size + j) * N, N);
     }
     hipFree(d_ct);
     return rc;
@@ -331,8 +346,10 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     if (rc == FHERAM_OK)
         rc = automorphism_key(-1, fheram_ctx::DNUM_GGSW, fheram_ctx::S_INV, (int)c->p.k_evk_ggsw_inv, c->d_atk_inv,
                               std_out ? std_out + (size_t)LOGN * fheram_ctx::ATK + fheram_ctx::EVK5 : nullptr);
-    hipFree(d_stage); hipFree(d_small); hipFree(d_hat);
-    std::fill(sk_out.begin(), sk_out.end(), 0); std::fill(ss.begin(), ss.end(), 0);
+    hipFree(d_stage);
+    wipe_free(c->stream, d_small, 2 * N * sizeof(int32_t));   // phi(s), s*s
+    wipe_free(c->stream, d_hat, N * sizeof(double));
+    wipe_host(sk_out.data(), sk_out.size() * sizeof(sk_out[0])); wipe_host(ss.data(), ss.size() * sizeof(ss[0]));
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
     c->keys_loaded = true;

@@ -60,23 +60,34 @@ class TorchComm:
         """what the engine takes: ndarray, or (device pointer, True)"""
         return (buf.data_ptr(), True) if self.device else buf
 
-    def all_gather(self, buf, n_glwe: int, glwe_len: int):
+    # Device mode: the evaluator enqueues on its own HIP stream, RCCL on torch's current stream.  The two
+    # are ordered with events (fheram_stream_signal / fheram_stream_wait); the host never blocks.
+    def _stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def engine_done(self, engine):
+        """the collective that follows must see what the engine has enqueued so far"""
         if self.device:
-            out = self.torch.empty((self.world * n_glwe, glwe_len), dtype=self.torch.int32, device="cuda")
+            engine.stream_signal(self._stream())
+
+    def engine_next(self, engine):
+        """what the engine enqueues next must see the collective's result"""
+        if self.device:
+            engine.stream_wait(self._stream())
+
+    def all_gather(self, buf, out):
+        """out: [world * n_glwe][glwe_len], persistent (the engine reads it asynchronously)"""
+        if self.device:
             self.dist.all_gather_into_tensor(out, buf)
-            # RCCL ran on torch's stream, the evaluator uses its own: finish the collective before the
-            # engine reads the gathered buffer (the engine synchronises its stream before handing `buf` over)
-            self.torch.cuda.synchronize()
             return out
         t = self.torch.from_numpy(buf)
-        outs = [self.torch.empty_like(t) for _ in range(self.world)]
+        outs = [self.torch.from_numpy(out[r * buf.shape[0]:(r + 1) * buf.shape[0]]) for r in range(self.world)]
         self.dist.all_gather(outs, t)
-        return np.concatenate([o.numpy() for o in outs])
+        return out
 
     def broadcast(self, buf, root: int):
         if self.device:
             self.dist.broadcast(buf, src=root)
-            self.torch.cuda.synchronize()
             return buf
         t = self.torch.from_numpy(buf)
         self.dist.broadcast(t, src=root)
@@ -86,8 +97,8 @@ class TorchComm:
 class ShardedRam:
     """Ram::read / read_prepare_write / write (ram.rs:172-294) over a row-sharded RAM; one instance per rank.
 
-    engine: object with read_partial / read_finish / write_root / write_shard (fheram_amd.Ram created
-            with shard/n_shards) and .params."""
+    engine: object with read_partial / read_finish / write_begin / write_root / write_shard (fheram_amd.Ram
+            created with shard/n_shards; device buffers also need stream_signal / stream_wait) and .params."""
 
     def __init__(self, engine, comm: TorchComm, root: int = 0, download: bool = True):
         """download=False leaves the result of a read on the root's device (engine.result() fetches it)."""
@@ -95,13 +106,17 @@ class ShardedRam:
         p = engine.params
         self.ws, self.glen = p.word_size(), p.glwe_len()
         self._part = comm.alloc(self.ws, self.glen)
+        self._gath = comm.alloc(comm.world * self.ws, self.glen)
         self._ctlo = comm.alloc(self.ws, self.glen)
 
     def _read(self, address, keys, prepare_write):
         c = self.comm
+        c.engine_next(self.engine)        # an earlier collective may still be reading _part
         self.engine.read_partial(address, keys, prepare_write, out=c.handle(self._part))
-        gathered = c.all_gather(self._part, self.ws, self.glen)          # the one exchange step of a read
+        c.engine_done(self.engine)        # also orders the gather behind an earlier read_finish that reads _gath
+        gathered = c.all_gather(self._part, self._gath)                  # the one exchange step of a read
         if c.rank == self.root:
+            c.engine_next(self.engine)
             return self.engine.read_finish(address, keys, c.handle(gathered), prepare_write, download=self.download)
         return None
 
@@ -113,7 +128,10 @@ class ShardedRam:
 
     def write(self, w, address, keys):
         c = self.comm
+        self.engine.write_begin(address, keys)     # trace(ct_hi) of the local rows + inverse of coordinate 0: no ct_lo needed
         if c.rank == self.root:
             self.engine.write_root(w, address, keys, out=c.handle(self._ctlo))
+        c.engine_done(self.engine)                 # root: ct_lo is ready; others: an earlier write_shard has read _ctlo
         c.broadcast(self._ctlo, self.root)                                # the one exchange step of a write
+        c.engine_next(self.engine)
         self.engine.write_shard(address, keys, c.handle(self._ctlo))

@@ -121,6 +121,18 @@ int fheram_sync(fheram_ctx* ctx);
  * [limb][col][N] order (*_on_device = 1; the pointer must be valid on the context's device —
  * this is what an RCCL collective moves). */
 int fheram_ctx_create_sharded(const fheram_params* params, int device, int shard, int n_shards, fheram_ctx** out);
+/* Stream ordering for DEVICE buffers (*_on_device = 1).  The evaluator enqueues on its own HIP stream;
+ * a collective (RCCL) runs on the caller's.  Hand-overs of device buffers are asynchronous: no call
+ * below blocks the host for them.  The caller orders the two streams with events instead:
+ *   fheram_stream_signal(ctx, s): work enqueued on s AFTER this call waits for everything the context
+ *                                 has enqueued so far (call it after fheram_read_partial / fheram_write_root,
+ *                                 before the collective);
+ *   fheram_stream_wait(ctx, s):   work the context enqueues AFTER this call waits for everything enqueued
+ *                                 on s so far (call it after the collective, before fheram_read_finish /
+ *                                 fheram_write_shard).
+ * s is a hipStream_t (NULL = the legacy default stream).  Host buffers (*_on_device = 0) need neither. */
+int fheram_stream_signal(fheram_ctx* ctx, void* hip_stream);
+int fheram_stream_wait(fheram_ctx* ctx, void* hip_stream);
 int fheram_shard_info(const fheram_ctx* ctx, int* shard, int* n_shards, size_t* local_rows);
 /* Every shard.  out: word_size partial GLWEs.  prepare_write != 0 keeps the rotated rows (ram.rs:502-504). */
 int fheram_read_partial(fheram_ctx* ctx, const fheram_addr* addr, int prepare_write, void* out, int out_on_device);
@@ -130,6 +142,11 @@ int fheram_read_finish(fheram_ctx* ctx, const fheram_addr* addr, int prepare_wri
 /* Root: write_first_step + inverse coordinate-1 products (ram.rs:254-256,260-271,610).  ct_lo_out:
  * word_size GLWEs to broadcast. */
 int fheram_write_root(fheram_ctx* ctx, const int64_t* w, int n_w, const fheram_addr* addr, void* ct_lo_out, int out_on_device);
+/* Every shard, optional: start the part of a write that does not depend on ct_lo — trace(ct_hi) of the
+ * local rows (ram.rs:616) and the inversion of coordinate 0 (ram.rs:278-289) — so that it runs while the
+ * root computes ct_lo and the broadcast is in flight.  fheram_write_root and fheram_write_shard start
+ * it themselves when it has not been started. */
+int fheram_write_begin(fheram_ctx* ctx, const fheram_addr* addr);
 /* Every shard: write_mid_step on its rows with the broadcast ct_lo, then write_last_step (ram.rs:612-630,644-648). */
 int fheram_write_shard(fheram_ctx* ctx, const fheram_addr* addr, const void* ct_lo, int on_device);
 

@@ -9,6 +9,8 @@
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this code.
 #pragma once
+#include <atomic>
+#include <exception>
 #include "znx.hpp"
 #include "ntt.hpp"
 #include <algorithm>
@@ -123,10 +125,22 @@ static inline int64_t galois_inverse(int log_n, int64_t p) {
 struct Ctx {
     Params p;
     Ntt ntt;
-    int64_t max_big = 0;   // largest |coefficient| of any post-inverse-transform value (A.9)
-    uint64_t n_ep = 0, n_ks = 0, n_prepare = 0;
+    // statistics are atomics: the all-core variant (threads > 1, below) updates them from several threads
+    std::atomic<int64_t> max_big{0};   // largest |coefficient| of any post-inverse-transform value (A.9)
+    std::atomic<uint64_t> n_ep{0}, n_ks{0}, n_prepare{0};
+    // threads > 1: the all-core CPU baseline.  Sub-RAMs are independent (ram.rs:187-190 maps
+    // over them one after the other) and so are the rows inside the per-row loops (ram.rs:429-434, 502-504,
+    // 612-630, 644-646); OpenMP runs those loops in parallel.  The packer stays sequential per sub-RAM, as
+    // in the reference.  Results are identical to threads = 1 (every ciphertext sees the same operations).
+    int threads = 1;
     explicit Ctx(const Params& p_) : p(p_), ntt(p_.log_n) {}
     int n() const { return p.n(); }
+    void note_big(int64_t mx) {
+        int64_t cur = max_big.load(std::memory_order_relaxed);
+        while (mx > cur && !max_big.compare_exchange_weak(cur, mx, std::memory_order_relaxed)) {}
+    }
+    int outer_threads() const { return std::max(1, std::min(threads, (int)p.word_size)); }
+    int inner_threads() const { return std::max(1, threads / outer_threads()); }
 };
 static constexpr int64_t BIG_BOUND = (int64_t)1 << 47;   // HIP prime 2^48+57345 needs |big| < p/2
 
@@ -173,7 +187,7 @@ static inline void vmp_to_big(Ctx& c, Big& big, const std::vector<std::vector<co
             for (int ci = 0; ci < cols_in; ci++)
                 for (size_t r = 0; r < a_polys[ci].size(); r++) mac_hat(c.ntt, acc, ah[ci][r], M.at((int)r, ci, j, co));
             int64_t mx = from_hat(c.ntt, acc, big.at(co, j));
-            if (mx > c.max_big) c.max_big = mx;
+            c.note_big(mx);
         }
 }
 
@@ -503,12 +517,20 @@ struct Ram {                                                     // ram.rs:25-29
             coordinate_prepare(*c, cp, coordinate);                                   // :416-419
             if (i < address.n2() - 1) {
                 const size_t total = res_prev.size();
+                std::vector<std::vector<int64_t>> prod;   // all-core variant: the rows' products, computed in parallel up front
+                const int nth = c->inner_threads();
+                if (nth > 1) {
+                    prod.assign(total, std::vector<int64_t>(glen()));
+#pragma omp parallel for num_threads(nth) schedule(dynamic)
+                    for (size_t r = 0; r < total; r++) coordinate_product(*c, cp, view(prod[r]), view(res_prev[r]));
+                }
                 for (size_t base = 0; base < total; base += n) {                      // chunks(n) :424
                     const size_t chunk_len = std::min(n, total - base);
                     for (size_t j = 0; j < n; j++) {
                         size_t j_rev = reverse_bits_msb(j, (uint32_t)log_n);          // :426
                         if (j_rev < chunk_len) {
-                            coordinate_product(*c, cp, view(tmp_ct), view(res_prev[base + j_rev]));   // :429-434
+                            if (nth > 1) tmp_ct = prod[base + j_rev];
+                            else coordinate_product(*c, cp, view(tmp_ct), view(res_prev[base + j_rev]));   // :429-434
                             packer_add(*c, s.packer, tmp_ct.data(), keys.atk_glwe);   // :435
                         } else {
                             packer_add(*c, s.packer, nullptr, keys.atk_glwe);         // :437-443
@@ -539,7 +561,8 @@ struct Ram {                                                     // ram.rs:25-29
             std::vector<std::vector<int64_t>>& res_prev = (i == 0) ? s.data : s.tree[i - 1];   // :490-494
             CoordinatePrepared cp;
             coordinate_prepare(*c, cp, coordinate);                                   // :496-499
-            for (auto& poly : res_prev) coordinate_product_inplace(*c, cp, view(poly));   // :502-504
+#pragma omp parallel for num_threads(c->inner_threads()) schedule(dynamic)
+            for (size_t r = 0; r < res_prev.size(); r++) coordinate_product_inplace(*c, cp, view(res_prev[r]));   // :502-504
             if (i < address.n2() - 1) {
                 const size_t total = res_prev.size();
                 for (size_t base = 0; base < total; base += n) {                      // :510
@@ -583,6 +606,24 @@ struct Ram {                                                     // ram.rs:25-29
             std::vector<int64_t>& ct_lo = tree_lo[j];                                 // :608
             coordinate_product_inplace(*c, inv_coordinate, view(ct_lo));              // :610
             const size_t chunk_len = std::min(n, tree_hi.size() - base);
+            if (c->inner_threads() > 1) {
+                // all-core variant: iteration q sees ct_lo * X^-q (q rotations by X^-1 compose exactly), so the
+                // rows are independent
+                const std::vector<int64_t> ct_lo0 = ct_lo;
+#pragma omp parallel for num_threads(c->inner_threads()) schedule(dynamic)
+                for (size_t q = 0; q < chunk_len; q++) {
+                    std::vector<int64_t>& ct_hi = tree_hi[base + q];
+                    std::vector<int64_t> tmp_a = ct_hi, lo(ct_lo0.size());
+                    glwe_trace_inplace(*c, view(tmp_a), 0, log_n, keys.atk_glwe);
+                    glwe_sub_inplace(view(ct_hi), view(tmp_a));
+                    glwe_rotate(*c, -(int64_t)q, view(lo), view(const_cast<std::vector<int64_t>&>(ct_lo0)));
+                    glwe_trace_inplace(*c, view(lo), 0, log_n, keys.atk_glwe);
+                    glwe_add_inplace(view(ct_hi), view(lo));
+                    glwe_normalize_inplace(*c, view(ct_hi));
+                }
+                glwe_rotate(*c, -(int64_t)chunk_len, view(ct_lo), view(const_cast<std::vector<int64_t>&>(ct_lo0)));
+                continue;
+            }
             for (size_t q = 0; q < chunk_len; q++) {                                  // :612
                 std::vector<int64_t>& ct_hi = tree_hi[base + q];
                 std::vector<int64_t> tmp_a = ct_hi;
@@ -598,33 +639,51 @@ struct Ram {                                                     // ram.rs:25-29
     }
     // SubRam::write_last_step, ram.rs:634-649
     void write_last_step(SubRam& s, const CoordinatePrepared& inv_coordinate) {
-        for (auto& ct_lo : s.data) coordinate_product_inplace(*c, inv_coordinate, view(ct_lo));   // :644-646
+#pragma omp parallel for num_threads(c->inner_threads()) schedule(dynamic)
+        for (size_t r = 0; r < s.data.size(); r++) coordinate_product_inplace(*c, inv_coordinate, view(s.data[r]));   // :644-646
         s.state = false;                                                              // :648
+    }
+
+    // the reference maps over the sub-RAMs one after the other (ram.rs:187-190); with Ctx::threads > 1 they run
+    // concurrently (first exception wins, as a panic would)
+    template <typename F>
+    void par_subrams(F&& f) {
+        const int nt = c->outer_threads();
+        if (nt <= 1) { for (size_t i = 0; i < subrams.size(); i++) f(i); return; }
+        std::exception_ptr err;
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+        for (size_t i = 0; i < subrams.size(); i++) {
+            try { f(i); } catch (...) {
+#pragma omp critical
+                if (!err) err = std::current_exception();
+            }
+        }
+        if (err) std::rethrow_exception(err);
     }
 
     // Ram::read, ram.rs:172-191.  out: word_size GLWEs.
     void read(const Address& address, const EvaluationKeysPrepared& keys, int64_t* out) {
         if (subrams.empty() || subrams[0].data.empty()) throw std::runtime_error("unitialized memory: self.data.len()=0");   // :182-185
-        for (size_t i = 0; i < subrams.size(); i++) subram_read(subrams[i], address, keys, out + i * glen());
+        par_subrams([&](size_t i) { subram_read(subrams[i], address, keys, out + i * glen()); });
     }
     // Ram::read_prepare_write, ram.rs:196-222
     void read_prepare_write(const Address& address, const EvaluationKeysPrepared& keys, int64_t* out) {
         if (subrams.empty() || subrams[0].data.empty()) throw std::runtime_error("unitialized memory: self.data.len()=0");   // :206-209
-        for (size_t i = 0; i < subrams.size(); i++) subram_read_prepare_write(subrams[i], address, keys, out + i * glen());
+        par_subrams([&](size_t i) { subram_read_prepare_write(subrams[i], address, keys, out + i * glen()); });
     }
     // Ram::write, ram.rs:226-294
     void write(const int64_t* w, size_t n_w, const Address& address, const EvaluationKeysPrepared& keys) {
         if (n_w != subrams.size()) throw std::runtime_error("w.len() != subrams.len()");   // :243
-        for (size_t i = 0; i < subrams.size(); i++) write_first_step(subrams[i], w + i * glen(), address.n2(), keys);   // :254-256
+        par_subrams([&](size_t i) { write_first_step(subrams[i], w + i * glen(), address.n2(), keys); });   // :254-256
         for (size_t ii = address.n2() - 1; ii-- > 0;) {                               // (0..n2-1).rev() :258
             const Coordinate& coordinate = address.at(ii + 1);                        // :260
             CoordinatePrepared inv;
             coordinate_prepare_inv(*c, inv, coordinate, keys.atk_ggsw_inv, keys.tsk_ggsw_inv);   // :265-271
-            for (auto& s : subrams) write_mid_step(s, ii, inv, keys);                 // :273-275
+            par_subrams([&](size_t i) { write_mid_step(subrams[i], ii, inv, keys); });   // :273-275
         }
         CoordinatePrepared inv0;
         coordinate_prepare_inv(*c, inv0, address.at(0), keys.atk_ggsw_inv, keys.tsk_ggsw_inv);   // :278-289
-        for (auto& s : subrams) write_last_step(s, inv0);                             // :291-293
+        par_subrams([&](size_t i) { write_last_step(subrams[i], inv0); });            // :291-293
     }
 };
 

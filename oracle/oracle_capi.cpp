@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/README.md).
 // C entry points (ctypes) over the C++ restatement.  Loaded only by tests/, smoke() and
 // bench.py's cpu_baseline leg through oracle/pyoracle.py.
+#include <omp.h>
 #include "setup.hpp"
 #include <string>
 
@@ -31,6 +32,9 @@ void* fo_ctx_new(int log_n, int base2k, int k_pt, int k_ct, int k_addr, int k_ev
 void fo_ctx_free(void* c) { delete (Ctx*)c; }
 int64_t fo_ctx_max_big(void* c) { return ((Ctx*)c)->max_big; }
 void fo_ctx_reset_stats(void* c) { Ctx* x = (Ctx*)c; x->max_big = 0; x->n_ep = x->n_ks = x->n_prepare = 0; }
+// all-core variant: sub-RAMs and the rows of the per-row loops run on `threads` OpenMP threads
+void fo_ctx_set_threads(void* c, int threads) { ((Ctx*)c)->threads = threads < 1 ? 1 : threads; omp_set_max_active_levels(2); }
+int fo_ctx_threads(void* c) { return ((Ctx*)c)->threads; }
 void fo_ctx_counters(void* c, uint64_t* out) { Ctx* x = (Ctx*)c; out[0] = x->n_ep; out[1] = x->n_ks; out[2] = x->n_prepare; }
 
 // ---- base.rs / lib.rs -------------------------------------------------------------

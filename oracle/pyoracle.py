@@ -42,6 +42,8 @@ def lib():
         L.fo_ctx_max_big.argtypes = [C.c_void_p]
         L.fo_ctx_reset_stats.argtypes = [C.c_void_p]
         L.fo_ctx_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.fo_ctx_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.fo_ctx_threads.argtypes = [C.c_void_p]
         L.fo_base1d_max.restype = C.c_uint64
         L.fo_base1d_max.argtypes = [U8P, C.c_int]
         L.fo_base1d_gap.restype = C.c_uint64
@@ -300,6 +302,11 @@ class Oracle:
 
     def reset_stats(self):
         lib().fo_ctx_reset_stats(self.h)
+
+    def set_threads(self, threads: int):
+        """all-core variant of the Ram ops (OpenMP over sub-RAMs and rows; same results as 1 thread)"""
+        lib().fo_ctx_set_threads(self.h, int(threads))
+        return self
 
     # -- setup (examples/fhe-ram.rs:34-95)
     def secret_gen(self, seed):

@@ -61,6 +61,9 @@ class OracleShardEngine:
             self.tree = tree
         return out
 
+    def write_begin(self, address, keys):
+        pass   # the HIP engine starts its ct_lo-independent work here; nothing to overlap on the CPU
+
     def write_root(self, w, address, keys, out=None):
         w = np.asarray(w, dtype=np.int64).reshape(self.ws, -1)
         inv = [self.o.ggsw_automorphism_inv(keys, g) for g in self._digits(address, 1)]

@@ -13,9 +13,11 @@ itself stays unpinned (oracle/README.md).
   znx_kat.json : small known-answer vectors of the limb arithmetic (normalise, rsh, rotate,
       automorphism).
   digests_n4096.json : SHA-256 of inputs and outputs of the same flow at N = 4096
-      (MAX_ADDR = 2^12 and 2^14), inputs regenerated from the recorded seeds.
+      (MAX_ADDR = 2^12, 2^14 and the full BASELINE.json sizes 2^18 and 2^21, WORDSIZE = 4), inputs
+      regenerated from the recorded seeds.  The two full sizes run the oracle's all-core variant
+      (same results as one thread, tests/test_oracle.py); 2^21 takes a few minutes on 8 cores.
 
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py [--small-only]
 """
 import hashlib
 import json
@@ -34,21 +36,33 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int64).tobytes()).hexdigest()
 
 
-def flow(params, seed):
-    """Runs the example flow on the oracle; returns (inputs, outputs) dicts of int64 arrays."""
-    o = po.Oracle(params)
+def inputs(params, seed, o=None):
+    """Inputs of the example flow from the oracle's setup side (seeded): keys, RAM, address, word."""
+    o = o or po.Oracle(params)
     p = o.p
     sk = o.secret_gen(seed)
     evk = o.evk_gen(sk, seed + 1, seed + 2)
-    keys = o.keys_prepare(evk)
     rng = np.random.default_rng(seed + 3)
     data = rng.integers(0, 256, size=p.max_addr * p.word_size, dtype=np.uint8)
     rows = o.ram_encrypt(data, sk, seed + 4, seed + 5)
     idx = int(rng.integers(0, p.max_addr))
     addr_g = o.address_encrypt(idx, sk, seed + 6, seed + 7)
-    addr = o.address_new(addr_g)
     val = rng.integers(0, 256, size=p.word_size, dtype=np.uint8)
     w = np.stack([o.glwe_encrypt_coeff0(int(v), sk, seed + 8 + i, seed + 40 + i) for i, v in enumerate(val)])
+    return {"sk": sk, "gal_els": evk["gal_els"], "atk_glwe": evk["atk_glwe"], "atk_ggsw_inv": evk["atk_ggsw_inv"],
+            "tsk": evk["tsk"], "data": data.astype(np.int64), "rows": rows, "idx": np.array([idx], dtype=np.int64),
+            "addr": addr_g, "val": val.astype(np.int64), "w": w}
+
+
+def flow(params, seed, threads=1):
+    """Runs the example flow on the oracle; returns (inputs, outputs) dicts of int64 arrays."""
+    o = po.Oracle(params).set_threads(threads)
+    p = o.p
+    inp = inputs(params, seed, o)
+    sk, rows, addr_g, w = inp["sk"], inp["rows"], inp["addr"], inp["w"]
+    data, val, idx = inp["data"].astype(np.uint8), inp["val"].astype(np.uint8), int(inp["idx"][0])
+    keys = o.keys_prepare({k: inp[k] for k in ("gal_els", "atk_glwe", "atk_ggsw_inv", "tsk")})
+    addr = o.address_new(addr_g)
     ram = o.ram_new()
     ram.load(rows)
     out = {}
@@ -61,9 +75,6 @@ def flow(params, seed):
     ram.write(w, addr, keys)
     out["rows_after_write"] = ram.store()
     out["readback"] = ram.read(addr, keys)
-    inp = {"sk": sk, "gal_els": evk["gal_els"], "atk_glwe": evk["atk_glwe"], "atk_ggsw_inv": evk["atk_ggsw_inv"],
-           "tsk": evk["tsk"], "data": data.astype(np.int64), "rows": rows, "idx": np.array([idx], dtype=np.int64),
-           "addr": addr_g, "val": val.astype(np.int64), "w": w}
     # decrypt checks (the reference's own assertion) so a fixture can never freeze a wrong answer
     newdata = data.copy()
     for i in range(p.word_size):
@@ -109,12 +120,17 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"flow_n{1 << log_n}.npz"), meta=meta,
                             **{"in_" + k: v for k, v in inp.items()}, **{"out_" + k: v for k, v in out.items()})
     json.dump(znx_kat(), open(os.path.join(HERE, "znx_kat.json"), "w"))
-    dig = {}
-    for max_addr, ws, seed in ((1 << 12, 4, 3000), (1 << 14, 2, 4000)):
-        inp, out, o = flow(po.OParams(max_addr=max_addr, word_size=ws), seed)
+    path = os.path.join(HERE, "digests_n4096.json")
+    dig = json.load(open(path)) if os.path.exists(path) else {}
+    sizes = [(1 << 12, 4, 3000), (1 << 14, 2, 4000)]
+    if "--small-only" not in sys.argv:
+        sizes += [(1 << 18, 4, 5000), (1 << 21, 4, 6000)]     # BASELINE.json configs[2..4]
+    for max_addr, ws, seed in sizes:
+        inp, out, o = flow(po.OParams(max_addr=max_addr, word_size=ws), seed, threads=os.cpu_count() or 1)
         dig[str(max_addr)] = {"word_size": ws, "seed": seed, "max_big_log2": float(np.log2(o.max_big())),
                               "inputs": {k: sha(v) for k, v in inp.items()}, "outputs": {k: sha(v) for k, v in out.items()}}
-    json.dump(dig, open(os.path.join(HERE, "digests_n4096.json"), "w"), indent=1)
+        json.dump(dig, open(path, "w"), indent=1)
+        print("digests for max_addr", max_addr, "done", flush=True)
     print("golden fixtures written to", HERE)
 
 

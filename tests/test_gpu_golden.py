@@ -1,6 +1,11 @@
 """HIP path against the committed golden digests (tests/golden/digests_n4096.json): inputs are
 regenerated from the recorded seeds by the oracle's setup side, the GPU runs the example flow, and
-the SHA-256 of every output must equal the committed one."""
+the SHA-256 of every output must equal the committed one.
+
+Covers BASELINE.json's full sizes: configs[2..3] (MAX_ADDR = 2^18: read, read_prepare_write, the rows
+and the tree after it, the rows after write, the read-back) and configs[4] (MAX_ADDR = 2^21, rows
+sharded over 8 shard contexts, exchanged through DEVICE buffers as RCCL would move them), each
+against the digests the oracle produced in the build container (tests/golden/make_golden.py)."""
 import hashlib
 import json
 import os
@@ -19,23 +24,102 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int64).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("max_addr", [1 << 12, 1 << 14])
-def test_hip_flow_matches_committed_digests(po, max_addr):
+_INPUTS = {}
+
+
+def golden_inputs(po, max_addr):
+    """inputs of the committed flow, regenerated from its seeds (setup side of the oracle only)"""
+    if max_addr in _INPUTS:
+        return _INPUTS[max_addr]
     sys.path.insert(0, GOLD)
     import make_golden
-    pkg = load_package()
     d = json.load(open(os.path.join(GOLD, "digests_n4096.json")))[str(max_addr)]
-    ws = d["word_size"]
-    inp, _, _ = make_golden.flow(po.OParams(max_addr=max_addr, word_size=ws), d["seed"])
+    inp = make_golden.inputs(po.OParams(max_addr=max_addr, word_size=d["word_size"]), d["seed"])
     assert {k: sha(v) for k, v in inp.items()} == d["inputs"], "setup side not reproducible on this machine"
+    _INPUTS.clear()            # one size at a time: the 2^21 RAM is 400 MB of int64
+    _INPUTS[max_addr] = (d, inp)
+    return d, inp
+
+
+@pytest.mark.parametrize("max_addr", [1 << 12, 1 << 14, 1 << 18, 1 << 21])
+def test_hip_flow_matches_committed_digests(po, max_addr):
+    pkg = load_package()
+    d, inp = golden_inputs(po, max_addr)
+    ws = d["word_size"]
     ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr)
     keys = pkg.EvaluationKeysPrepared(inp["gal_els"], list(inp["atk_glwe"]), inp["atk_ggsw_inv"], inp["tsk"])
     addr = pkg.Address(ram.params, list(inp["addr"]))
     ram.load_encrypted(inp["rows"])
-    out = {"read": ram.read(addr, keys), "rpw": ram.read_prepare_write(addr, keys), "rows_after_rpw": ram.store_encrypted()}
+    out = {"read": sha(ram.read(addr, keys)), "rpw": sha(ram.read_prepare_write(addr, keys)),
+           "rows_after_rpw": sha(ram.store_encrypted())}
     if max_addr > 4096:
-        out["tree_after_rpw"] = ram.tree(0)
+        out["tree_after_rpw"] = sha(ram.tree(0))
     ram.write(inp["w"], addr, keys)
-    out["rows_after_write"] = ram.store_encrypted()
-    out["readback"] = ram.read(addr, keys)
-    assert {k: sha(v) for k, v in out.items()} == d["outputs"]
+    out["rows_after_write"] = sha(ram.store_encrypted())
+    out["readback"] = sha(ram.read(addr, keys))
+    assert out == d["outputs"]
+
+
+@pytest.mark.parametrize("n_shards,max_addr,device_buffers",
+                         [(8, 1 << 18, False), (8, 1 << 18, True), (8, 1 << 21, True), (2, 1 << 21, False)])
+def test_sharded_flow_matches_committed_digests(po, n_shards, max_addr, device_buffers):
+    """BASELINE.json configs[4]: one RAM, rows sharded over n_shards contexts (here all on one GPU; one
+    process per GPU in production, fheram_amd.sharded).  One all-gather per read, one broadcast per write.
+    device_buffers: the exchanged GLWEs stay int32 in device memory (what RCCL moves) and the contexts'
+    streams are ordered with fheram_stream_signal / fheram_stream_wait — no host synchronisation."""
+    pkg = load_package()
+    d, inp = golden_inputs(po, max_addr)
+    ws = d["word_size"]
+    G = n_shards
+    params = pkg.Parameters(max_addr=max_addr, word_size=ws)
+    glen = params.glwe_len()
+    keys = pkg.EvaluationKeysPrepared(inp["gal_els"], list(inp["atk_glwe"]), inp["atk_ggsw_inv"], inp["tsk"])
+    shards = [pkg.Ram(params, 0, shard=g, n_shards=G) for g in range(G)]
+    addrs = [pkg.Address(params, list(inp["addr"])) for _ in shards]
+    for g, r in enumerate(shards):
+        r.load_encrypted(inp["rows"][:, g::G])
+
+    if device_buffers:
+        import torch
+        parts = torch.zeros((G, ws, glen), dtype=torch.int32, device="cuda")
+        ctlo = torch.zeros((ws, glen), dtype=torch.int32, device="cuda")
+        xs = torch.cuda.current_stream().cuda_stream        # stands for the collective's stream
+        torch.cuda.synchronize()
+
+        def read(prepare_write):
+            for g, (r, a) in enumerate(zip(shards, addrs)):
+                r.read_partial(a, keys, prepare_write, out=(parts[g].data_ptr(), True))
+                r.stream_signal(xs)                         # "all-gather" = the shards wrote their slices in place
+            shards[0].stream_wait(xs)
+            return shards[0].read_finish(addrs[0], keys, (parts.data_ptr(), True), prepare_write)
+
+        def write(w):
+            for r, a in zip(shards, addrs):
+                r.write_begin(a, keys)
+            shards[0].write_root(w, addrs[0], keys, out=(ctlo.data_ptr(), True))
+            shards[0].stream_signal(xs)                     # "broadcast"
+            for r, a in zip(shards, addrs):
+                r.stream_wait(xs)
+                r.write_shard(a, keys, (ctlo.data_ptr(), True))
+    else:
+        def read(prepare_write):
+            partials = np.stack([r.read_partial(a, keys, prepare_write) for r, a in zip(shards, addrs)])
+            return shards[0].read_finish(addrs[0], keys, partials, prepare_write)
+
+        def write(w):
+            ct_lo = shards[0].write_root(w, addrs[0], keys)
+            for r, a in zip(shards, addrs):
+                r.write_shard(a, keys, ct_lo)
+
+    def rows():
+        full = np.empty((ws, params.rows(), glen), dtype=np.int64)
+        for g, r in enumerate(shards):
+            full[:, g::G] = r.store_encrypted()
+        return full
+
+    out = {"read": sha(read(False)), "rpw": sha(read(True)), "rows_after_rpw": sha(rows()),
+           "tree_after_rpw": sha(shards[0].tree(0))}
+    write(inp["w"])
+    out["rows_after_write"] = sha(rows())
+    out["readback"] = sha(read(False))
+    assert out == d["outputs"]

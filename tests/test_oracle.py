@@ -229,3 +229,37 @@ def test_state_machine_and_size_asserts(po):  # ram.rs:393-396,555-558,243; coor
         ram.write(rows[:1, 0], addr, keys)
     with pytest.raises(po.OracleError, match="max_addr"):
         o.ram_encrypt(np.arange(64, dtype=np.uint8), sk, 4, 5)
+
+
+def test_all_core_variant_equals_one_thread(po):
+    """The OpenMP variant of the oracle's Ram ops (cpu_baseline_allcores in bench.py, golden digests of the
+    full sizes) runs sub-RAMs and rows concurrently; every ciphertext sees the same operations, so the
+    results must be identical to the sequential restatement."""
+    import numpy as np
+    outs = []
+    for th in (1, 4):
+        o = po.Oracle(po.OParams(max_addr=5 * 4096, word_size=2)).set_threads(th)
+        sk = o.secret_gen(1)
+        keys = o.keys_prepare(o.evk_gen(sk, 2, 3))
+        rng = np.random.default_rng(4)
+        data = rng.integers(0, 256, size=5 * 4096 * 2, dtype=np.uint8)
+        ram = o.ram_new()
+        ram.load(o.ram_encrypt(data, sk, 5, 6))
+        addr = o.address_new(o.address_encrypt(3 * 4096 + 17, sk, 7, 8))
+        w = np.stack([o.glwe_encrypt_coeff0(5 + i, sk, 9 + i, 19 + i) for i in range(2)])
+        r = [ram.read(addr, keys), ram.read_prepare_write(addr, keys), ram.store(), ram.tree(0)]
+        ram.write(w, addr, keys)
+        r += [ram.store(), ram.tree(0), ram.read(addr, keys)]
+        outs.append((r, o.counters(), o.max_big()))
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+
+
+def test_committed_digests_cover_the_full_sizes():
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "digests_n4096.json")))
+    for size in ("4096", "16384", "262144", "2097152"):      # BASELINE.json configs[0], source default, configs[2..3], configs[4]
+        assert {"read", "rpw", "rows_after_rpw", "rows_after_write", "readback"} <= set(d[size]["outputs"])
+        assert d[size]["max_big_log2"] < 47
