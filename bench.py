@@ -13,8 +13,15 @@ evaluation keys and the written words): the work of every kernel is data indepen
 setup code is timed.  Everything is resident in HBM before the timed region starts.
 
 N > 1 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`): one process
-per GPU, each rank owns an independent 2^18 RAM (RAM instances are the independent units of this
-path: an op needs `&mut Ram`); no data-path collective; weak scaling.
+per GPU and ONE RAM whose rows are sharded over the ranks (BASELINE.json configs[4]):
+one RCCL all-gather per read, one broadcast per write.  Default = weak scaling, 2^18 entries per GPU
+(N = 8 is exactly configs[4]: MAX_ADDR = 2^21 over 8 GPUs); `value` then counts an op on the
+N*2^18-entry RAM as N ops of the metric's size, so that value(N) / (N * value(1)) = T(1) / T(N) is the
+weak-scaling efficiency.  `--total-log-max-addr 21` fixes the RAM instead (strong scaling, value = raw
+RAM ops/s).  `--mode replicas` = N independent 2^18 RAMs, no collective (opt-in).
+
+`--workload ep` = BASELINE.json configs[1]: one GLWE x GGSW external product (latency) and a
+batch-256 launch (throughput).
 """
 import argparse
 import json
@@ -69,27 +76,26 @@ def algorithmic_bytes(max_addr, ws, n_digits):
     return read, rpw, write
 
 
-def pmc_traffic_per_launch(kernel_prefix):
-    """HBM bytes per launch of a kernel class from the committed PMC profile (None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+PMC_PROFILE = "profiles/r02_pmc_hbm_traffic.json"
+
+
+def pmc_traffic_per_launch():
+    """HBM bytes per launch of the dominant kernel shape (batch-256 fused trace step) from the committed
+    PMC profile of this command (tools/pmc_summary.py; None if absent)."""
+    path = os.path.join(ROOT, PMC_PROFILE)
     if not os.path.exists(path):
         return None
-    tot, n = 0.0, 0
-    for k, v in json.load(open(path)).items():
-        if kernel_prefix in k and isinstance(v, dict) and "FETCH_SIZE_per_launch" in v and "WRITE_SIZE_per_launch" in v:
-            tot += v["launches"] * (2.0 * v["FETCH_SIZE_per_launch"] + v["WRITE_SIZE_per_launch"]) * 1024.0
-            if "_norm" not in k:      # the normalisation pass of a limb-parallel op belongs to the same launch of the class
-                n += v["launches"]
-    return tot / n if n else None
+    return json.load(open(path)).get("dominant_kernel", {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(max_addr, seed):
-    """Times the oracle (CPU restatement, kind 'port') on a bounded sample of the same workload:
-    ONE of the WORDSIZE sub-RAMs of the 2^18 RAM (sub-RAMs are processed one after the other by
-    the reference, ram.rs:187-190), one read + one read_prepare_write + one write, single thread."""
+def cpu_baseline(max_addr, ws, seed, threads):
+    """Times the oracle (CPU restatement, kind 'port') on the same workload: one read + one
+    read_prepare_write + one write.  threads == 1: ONE of the WORDSIZE sub-RAMs (the reference processes them
+    one after the other, ram.rs:187-190; scaled by the caller).  threads > 1: the whole RAM with the oracle's
+    OpenMP variant (sub-RAMs and the rows of the per-row loops in parallel)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    o = po.Oracle(po.OParams(max_addr=max_addr, word_size=1))
+    o = po.Oracle(po.OParams(max_addr=max_addr, word_size=ws)).set_threads(threads)
     p = o.p
     rng = np.random.default_rng(seed)
     evk = {"gal_els": np.array([int(po.lib().fo_galois_element(12, i)) for i in range(12)], dtype=np.int64),
@@ -98,8 +104,8 @@ def cpu_baseline(max_addr, seed):
     keys = o.keys_prepare(evk)
     addr = o.address_new(synth(rng, (o.n_digits, p.ggsw_len)))
     ram = o.ram_new()
-    ram.load(synth(rng, (1, p.rows, p.glwe_len)))
-    w = synth(rng, (1, p.glwe_len))
+    ram.load(synth(rng, (ws, p.rows, p.glwe_len)))
+    w = synth(rng, (ws, p.glwe_len))
     t0 = time.perf_counter()
     ram.read(addr, keys)
     t1 = time.perf_counter()
@@ -110,21 +116,87 @@ def cpu_baseline(max_addr, seed):
     return t1 - t0, t2 - t1, t3 - t2
 
 
+def host_cpu():
+    try:
+        return open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t")
+    except Exception:
+        return "?"
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def bench_ep(pkg, args):
+    """BASELINE.json configs[1]: single GLWE x GGSW external product at N = 4096."""
+    ram = pkg.Ram.new_from_ram_params(4, [3, 3, 3, 3], 1 << 12)
+    cus = ram.device_info()["compute_units"]
+    for _ in range(args.warmup):
+        ram.bench_external_product(1, 8)
+    lat = [ram.bench_external_product(1, 64) / 64 for _ in range(args.steps)]
+    thr = [ram.bench_external_product(cus, 32) / 32 for _ in range(args.steps)]
+    big = [ram.bench_external_product(8 * cus, 8) / 8 for _ in range(args.steps)]
+    lat_ms, thr_ms, big_ms = float(np.median(lat)), float(np.median(thr)), float(np.median(big))
+    ep_bytes = 2 * GLWE_I64 + GGSW_I64            # SURVEY.md 8(d): a + G + res, int64-limb layout
+    fp64_per_ep = 14 * 24576 * 8 + 48 * 4096 * 7
+    out = {"metric": "GLWE x GGSW external products per second at N=4096 (BASELINE.json configs[1])",
+           "value": cus / (thr_ms * 1e-3), "unit": "external products/s (batch = #CUs per launch)",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": thr_ms, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "glwe_external_product, N=4096, base2k=17, rank=1, GLWE size 3, GGSW size 4 / dnum 3"},
+           "latency_us_single_product": lat_ms * 1e3,
+           "batch_launch_us": {str(cus): thr_ms * 1e3, str(8 * cus): big_ms * 1e3},
+           "amortised_us_per_product": {str(cus): thr_ms * 1e3 / cus, str(8 * cus): big_ms * 1e3 / (8 * cus)},
+           "roofline": {"kernel": "k_ext_product<3,4,2,0> (one workgroup per product)", "bound": "hbm",
+                        "achieved": (cus * 2 * GLWE_I64 + GGSW_I64) / thr_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (cus * 2 * GLWE_I64 + GGSW_I64) / thr_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_single_product": ep_bytes},
+           "roofline_valu": {"bound": "valu_fp64", "achieved": cus * fp64_per_ep / (thr_ms * 1e-3) / 1e12,
+                             "peak": FP64_VALU_PEAK_TINSTR, "unit": "T FP64 instr/s",
+                             "frac": cus * fp64_per_ep / (thr_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR},
+           "device": ram.device_info()}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        o = po.Oracle(po.OParams(max_addr=1 << 12))
+        rng = np.random.default_rng(5)
+        a, g = synth(rng, o.p.glwe_len), synth(rng, o.p.ggsw_len)
+        o.glwe_external_product(a, g)
+        t0 = time.perf_counter()
+        n_cpu = 20
+        for _ in range(n_cpu):
+            o.glwe_external_product(a, g)          # includes the GGSW prepare (48 forward transforms) every call
+        dt = (time.perf_counter() - t0) / n_cpu
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "external products/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle glwe_external_product incl. GGSW prepare, {n_cpu} calls, {dt * 1e3:.2f} ms each",
+                               "host_cpu": host_cpu()}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-max-addr", type=int, default=18)
+    ap.add_argument("--workload", choices=["ram", "ep"], default="ram",
+                    help="ram = Ram::read / read_prepare_write / write (BASELINE.json configs[2..4], default); "
+                         "ep = single external-product microbenchmark (configs[1])")
+    ap.add_argument("--log-max-addr", type=int, default=18, help="log2 of the RAM entries PER GPU (weak scaling)")
+    ap.add_argument("--total-log-max-addr", type=int, default=None,
+                    help="log2 of the entries of the ONE RAM sharded over all GPUs, fixed as N grows (strong scaling; "
+                         "BASELINE.json configs[4] = 21)")
     ap.add_argument("--word-size", type=int, default=4)
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="N > 1: 'replicas' = one independent 2^log_max_addr RAM per GPU (default, weak scaling in RAM "
-                         "ops/s); 'sharded' = ONE RAM of N * 2^log_max_addr entries, rows sharded over the GPUs "
-                         "(BASELINE.json configs[4]); one RCCL all-gather per read, one broadcast per write")
+    ap.add_argument("--mode", choices=["auto", "sharded", "replicas"], default="auto",
+                    help="N > 1: 'sharded' (default) = ONE RAM, rows sharded over the GPUs, one RCCL all-gather per read "
+                         "and one broadcast per write; 'replicas' = one independent RAM per GPU, no collective")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the pass that includes the host hand-over")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,8 +204,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    mode = args.mode if args.mode != "auto" else ("sharded" if world > 1 else "single")
+    # the sharded path can be rehearsed with ONE rank (RCCL + device buffers + event hand-over) under torch.distributed.run
+    use_dist = world > 1 or (mode == "sharded" and "RANK" in os.environ)
+    if mode == "sharded" and not use_dist:
+        mode = "single"
     dist = None
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -145,21 +222,37 @@ def main():
 
     from _pkg import load_package
     pkg = load_package()
-    max_addr, ws = 1 << args.log_max_addr, args.word_size
-    sharded = args.mode == "sharded" and world > 1
+    if args.workload == "ep":
+        if rank == 0:
+            bench_ep(pkg, args)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ws = args.word_size
+    sharded = mode == "sharded"
+    strong = sharded and args.total_log_max_addr is not None
+    if strong:
+        max_addr = 1 << args.total_log_max_addr
+    elif sharded:
+        max_addr = (1 << args.log_max_addr) * world      # weak scaling of ONE RAM: 2^log_max_addr entries per GPU
+    else:
+        max_addr = 1 << args.log_max_addr
     if sharded:
-        max_addr *= world                      # weak scaling of ONE RAM: 2^log_max_addr entries per GPU
         ram = pkg.Ram(pkg.Parameters(max_addr=max_addr, word_size=ws), device=local_rank, shard=rank, n_shards=world)
     else:
         ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr, device=local_rank)
     p = ram.params
-    rng = np.random.default_rng(1234 + rank)
+    rng = np.random.default_rng(1234 + (0 if sharded else rank))     # sharded: every rank derives the same keys and address
     n_digits = p.base2d().as_1d().size()
     keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(synth(rng, (12, 3 * 4 * 2 * N))),
                                       synth(rng, 4 * 5 * 2 * N), synth(rng, 4 * 5 * 2 * N))
     addr = pkg.Address(p, list(synth(rng, (n_digits, p.ggsw_len()))))
+    rng = np.random.default_rng(4321 + rank)
     ram.load_encrypted(synth(rng, (ws, ram.local_rows(), p.glwe_len())))
-    ram.stage_words(synth(rng, (ws, p.glwe_len())))
+    words = synth(rng, (ws, p.glwe_len()))
+    ram.stage_words(words)
     if sharded:
         from fheram_amd.sharded import ShardedRam, TorchComm
         sram = ShardedRam(ram, TorchComm(device_buffers=args.dist_backend == "nccl"), download=False)
@@ -169,12 +262,12 @@ def main():
                lambda: ram.read_prepare_write(addr, keys, download=False),
                lambda: ram.write(None, addr, keys))
 
-    def step(timed):
+    def step():
         ts = []
         for fn in ops:
             ram.timer_begin()
             fn()
-            ts.append(ram.timer_end())
+            ts.append(ram.timer_end())     # HIP events on the context's stream; the host waits for the op here
         return ts
 
     def barrier():
@@ -185,10 +278,10 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     barrier()
     t0 = time.perf_counter()
-    per_op = [step(True) for _ in range(args.steps)]
+    per_op = [step() for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
     # Kernel-class durations for the roofline: the same K steps once more, now with every launch
@@ -200,10 +293,25 @@ def main():
         ram.profile_enable(True)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            step(True)
+            step()
         barrier()
         instr_elapsed = time.perf_counter() - t1
         ram.profile_enable(False)
+    # The same ops through the boundary's HOST buffers (int64 result out, int64 words in): host wall clock
+    # per call.  Never part of `value`.
+    boundary = None
+    if not args.no_boundary and not sharded:
+        bt = []
+        for _ in range(max(3, min(args.steps, 10))):
+            ts = []
+            for fn in (lambda: ram.read(addr, keys), lambda: ram.read_prepare_write(addr, keys), lambda: ram.write(words, addr, keys)):
+                a = time.perf_counter()
+                fn()
+                ram.sync()
+                ts.append((time.perf_counter() - a) * 1e3)
+            bt.append(ts)
+        boundary = np.median(np.array(bt), axis=0)
+        ram.stage_words(words)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
@@ -218,72 +326,100 @@ def main():
     per_op = np.array(per_op)              # [steps][3] ms, HIP events on the context's stream
     read_ms, rpw_ms, write_ms = per_op.mean(axis=0)
     ms_per_step = elapsed * 1e3 / args.steps
-    n_rams = 1 if sharded else world
-    ops_per_s = n_rams * 2 * args.steps / elapsed
+    n_rams = 1 if mode != "replicas" else world
+    raw_ops_per_s = n_rams * 2 * args.steps / elapsed
+    # weak scaling of ONE sharded RAM: an op on N*2^k entries counts as N ops of the 2^k-entry metric
+    weight = world if (sharded and not strong) else 1
+    log_entries = int(np.log2(max_addr)) if max_addr & (max_addr - 1) == 0 else float(np.log2(max_addr))
     a_read, a_rpw, a_write = algorithmic_bytes(max_addr, ws, n_digits)
     cnt = op_counts(max_addr, ws, p.base2d())
+    if mode == "replicas":
+        par = f"{world} independent RAMs of 2^{args.log_max_addr} entries, one per GPU, no data-path collective"
+    elif sharded:
+        par = (f"1 RAM of 2^{log_entries} entries, rows r = g (mod {world}) on GPU g; one RCCL all-gather per read, one "
+               f"broadcast per write ({'strong' if strong else 'weak'} scaling)")
+    else:
+        par = "1 RAM on 1 GPU"
 
     out = {
         "metric": f"encrypted RAM read ops/s + write ops/s at 2^{args.log_max_addr} entries; achieved HBM GB/s vs peak",
-        "value": ops_per_s, "unit": "RAM ops/s (1 read + 1 write[=rpw+write] per step)",
+        "value": raw_ops_per_s * weight,
+        "unit": "RAM ops/s (1 read + 1 write[=rpw+write] per step)" + (
+            f"; an op on the {world}*2^{args.log_max_addr}-entry sharded RAM counts as {world} ops of the 2^{args.log_max_addr}-entry metric" if weight > 1 else ""),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "mode": args.mode, "vs_baseline": None, "dtype": "f64", "arithmetic": "exact integers mod 2^48+57345 carried in FP64 (error-free products); int32 limbs in HBM",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "mode": mode, "vs_baseline": None, "dtype": "f64",
+        "arithmetic": "exact integers mod 2^48+57345 carried in FP64 (error-free products); int32 limbs in HBM",
         "data": "synthetic",
-        "config": {"workload": f"Ram::read + Ram::read_prepare_write + Ram::write, MAX_ADDR=2^{args.log_max_addr}, "
-                               f"WORDSIZE={ws}, N=4096, base2k=17, rank=1 (BASELINE.json configs[2]+[3])",
-                   "rams": n_rams, "rows_per_subram": cnt["rows"],
-                   "parallelism": (f"1 RAM of 2^{args.log_max_addr}*{world} entries, rows sharded over {world} GPUs (RCCL all-gather/broadcast)"
-                                   if sharded else f"{world} independent RAM(s), one per GPU")},
+        "config": {"workload": f"Ram::read + Ram::read_prepare_write + Ram::write, MAX_ADDR=2^{log_entries}, "
+                               f"WORDSIZE={ws}, N=4096, base2k=17, rank=1 (BASELINE.json configs[2]+[3]"
+                               + ("; configs[4] sharding" if sharded else "") + ")",
+                   "rams": n_rams, "rows_per_subram": cnt["rows"], "parallelism": par},
+        "ram_ops_s_raw": raw_ops_per_s,
         "read_ops_s": n_rams * 1e3 / read_ms, "write_ops_s": n_rams * 1e3 / (rpw_ms + write_ms),
         "read_ms": read_ms, "read_prepare_write_ms": rpw_ms, "write_ms": write_ms,
         "algorithmic_GBs_per_op": {"read": a_read / read_ms / 1e6, "read_prepare_write": a_rpw / rpw_ms / 1e6,
                                    "write": a_write / write_ms / 1e6},
-        "reference_published": {"read_ms": 450, "write_ms": 1200, "hw": "i9-12900K single thread (README.md:36)",
+        "reference_published": {"read_ms": 450, "write_ms": 1200, "hw": "i9-12900K single thread (README.md:36), 2^18 entries",
                                 "speedup_read": 450.0 / read_ms, "speedup_write": 1200.0 / write_ms},
         "device": ram.device_info(),
     }
+    if boundary is not None:
+        out["read_ms_incl_boundary"], out["rpw_ms_incl_boundary"], out["write_ms_incl_boundary"] = [float(x) for x in boundary]
+        out["boundary_note"] = ("host wall clock per call with the ABI's int64 host buffers: result download (ws GLWEs) on the two "
+                                "reads, word upload on write; median; not part of `value`")
 
     if not args.no_kernel_timing:
-        ks = ram.profile_get("keyswitch")
-        ep = ram.profile_get("ext_product")
-        pr = ram.profile_get("prepare")
-        el = ram.profile_get("elementwise")
-        # dominant kernel: the fused key-switch (trace step / packer combine).  Algorithmic bytes per
-        # block = input GLWE + output GLWE at the ABI's int64 width; the key (786 432 B) once per launch.
-        if ks["launches"]:
-            avg_ms = ks["ms"] / ks["launches"]
-            blocks = ks["blocks"] / ks["launches"]
-            bytes_per_launch = blocks * 2 * GLWE_I64 + ATK_I64
-            achieved = bytes_per_launch / avg_ms / 1e6
-            out["roofline"] = {"kernel": "k_keyswitch (glwe_automorphism family: trace step / packer combine)",
+        classes = {k: ram.profile_get(k) for k in ("keyswitch", "keyswitch_fused", "ext_product", "ext_product_fused", "prepare", "elementwise")}
+        kf = classes["keyswitch_fused"]
+        # Dominant kernel = the fused key-switch at one workgroup per ciphertext (trace step / packer level over every
+        # row of every sub-RAM): k_keyswitch<KS_TRACE,3,4,3,2,0>.  Its launches are timed on their own.
+        if kf["launches"]:
+            avg_ms = kf["ms"] / kf["launches"]
+            blocks = kf["blocks"] / kf["launches"]
+            bytes_abi = blocks * 2 * GLWE_I64 + ATK_I64              # in + out GLWE (int64 limbs) + key once
+            bytes_dev = blocks * 2 * (GLWE_I64 // 2) + ATK_I64       # what the device layout must move: int32 limbs, f64 key
+            achieved = bytes_abi / avg_ms / 1e6
+            fp64_per_block = 11 * 24576 * 8 + 24 * 4096 * 7         # 11 transforms x 24576 butterflies x 8 + 24 x 4096 MACs x 7
+            out["roofline"] = {"kernel": "k_keyswitch<KS_TRACE,3,4,3,NCO=2,STAGE=0> (fused trace step / packer level, one workgroup per ciphertext)",
                                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch("k_keyswitch"),
-                               "traffic_source": "profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                 "passes of this command; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, launch-weighted mean)",
-                               "avg_launch_ms": avg_ms, "avg_blocks_per_launch": blocks, "launches": ks["launches"],
-                               "algorithmic_bytes_per_launch": bytes_per_launch}
-            # companion VALU roofline: 11 transforms x 24576 butterflies x 8 FP64 ops + 24 x 4096 MACs x 7
-            fp64_per_block = 11 * 24576 * 8 + 24 * 4096 * 7
-            out["roofline_valu"] = {"bound": "valu_fp64", "achieved": ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12,
-                                    "peak": FP64_VALU_PEAK_TINSTR, "unit": "T FP64 instr/s",
-                                    "frac": ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR,
-                                    "measured_issue_peak": 36.0,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
+                               "traffic_source": PMC_PROFILE + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                                 "FETCH_SIZE scaled by the factor calibrated on a known-bytes 4-B/lane int32 stream, tools/fetch_calib.hip)",
+                               "avg_launch_ms": avg_ms, "avg_blocks_per_launch": blocks, "launches": kf["launches"],
+                               "algorithmic_bytes_per_launch": bytes_abi,
+                               "device_layout_bytes_per_launch": bytes_dev, "achieved_device_layout": bytes_dev / avg_ms / 1e6,
+                               "frac_device_layout": bytes_dev / avg_ms / 1e6 / HBM_PEAK_GBS,
+                               "note": "not HBM-bound: the binding roof is the FP64 vector ALU (roofline_valu)"}
+            ach = kf["blocks"] * fp64_per_block / (kf["ms"] * 1e-3) / 1e12
+            out["roofline_valu"] = {"kernel": "same launches", "bound": "valu_fp64", "achieved": ach, "peak": FP64_VALU_PEAK_TINSTR,
+                                    "unit": "T FP64 instr/s", "frac": ach / FP64_VALU_PEAK_TINSTR, "measured_issue_peak": 36.0,
                                     "measured_issue_peak_source": "profiles/r01_valu_rate.txt (tools/valu_rate.hip: mulmod chains sustain 1.8 ns per "
                                                                   "wave-instruction per SIMD at the 2.15 GHz clock of FP64 load)"}
-        out["kernel_classes"] = {"keyswitch": ks, "ext_product": ep, "prepare": pr, "elementwise": el}
+            ks = classes["keyswitch"]
+            if ks["launches"]:
+                cls = ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12
+                out["roofline_valu"]["whole_class"] = {"achieved": cls, "frac": cls / FP64_VALU_PEAK_TINSTR,
+                                                       "avg_launch_ms": ks["ms"] / ks["launches"], "avg_blocks_per_launch": ks["blocks"] / ks["launches"]}
+        out["kernel_classes"] = classes
         out["kernel_timing_pass"] = {"what": "separate pass of the same K steps with per-launch HIP events on the launch stream "
                                              "(not part of the timed region: the events add this much to a step)",
                                      "ms_per_step_instrumented": instr_elapsed * 1e3 / args.steps}
 
-    if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
-        r, q, w = cpu_baseline(max_addr, 99)
+    if not args.no_cpu_baseline and world == 1 and mode == "single":   # reported baseline: rank 0 at N = 1 only
+        r, q, w = cpu_baseline(max_addr, 1, 99, 1)
         # the sample is 1 of `ws` sub-RAMs: scale by ws (prepare_inv is shared, <1 % of a write)
         cpu_step_s = ws * (r + q + w)
         out["cpu_baseline"] = {"value": 2.0 / cpu_step_s, "unit": "RAM ops/s", "cores": 1, "kind": "port",
                                "sample": f"oracle (C++ exact-integer restatement), 1 of {ws} sub-RAMs of the 2^{args.log_max_addr} RAM: "
                                          f"read {r:.2f}s + read_prepare_write {q:.2f}s + write {w:.2f}s, scaled x{ws}",
                                "read_ms": ws * r * 1e3, "read_prepare_write_ms": ws * q * 1e3, "write_ms": ws * w * 1e3,
-                               "host_cpu": open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t") if os.path.exists("/proc/cpuinfo") else "?"}
+                               "host_cpu": host_cpu()}
+        cores = host_cores()
+        r, q, w = cpu_baseline(max_addr, ws, 99, cores)
+        out["cpu_baseline_allcores"] = {"value": 2.0 / (r + q + w), "unit": "RAM ops/s", "cores": cores, "kind": "port",
+                                        "sample": f"oracle, OpenMP over the {ws} sub-RAMs and the rows of the per-row loops (packer sequential per "
+                                                  f"sub-RAM, as in the reference), whole 2^{args.log_max_addr} RAM, one step",
+                                        "read_ms": r * 1e3, "read_prepare_write_ms": q * 1e3, "write_ms": w * 1e3, "host_cpu": host_cpu()}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

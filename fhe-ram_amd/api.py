@@ -100,6 +100,7 @@ _SYMBOLS = [
     ("fheram_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("fheram_profile_get", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     ("fheram_profile_reset", C.c_int, [C.c_void_p]),
+    ("fheram_bench_external_product", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("fheram_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
 ]
 
@@ -667,6 +668,12 @@ class Ram:
         a, b, ms = C.c_uint64(), C.c_uint64(), C.c_double()
         self._chk(library().fheram_profile_get(self._h, cls.encode(), C.byref(a), C.byref(b), C.byref(ms)))
         return {"launches": int(a.value), "blocks": int(b.value), "ms": float(ms.value)}
+
+    def bench_external_product(self, batch: int, iters: int) -> float:
+        """ms for a dependent chain of `iters` launches of `batch` GLWE x GGSW products (BASELINE.json configs[1])"""
+        ms = C.c_float()
+        self._chk(library().fheram_bench_external_product(self._h, batch, iters, C.byref(ms)))
+        return float(ms.value)
 
     def device_info(self):
         buf = C.create_string_buffer(256)

@@ -578,6 +578,33 @@ int fheram_debug_stamps(fheram_ctx* c, unsigned long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n > 64 ? 64 : n)) == hipSuccess ? 0 : 7;
 }
 #endif
+int fheram_bench_external_product(fheram_ctx* c, int batch, int iters, float* total_ms) {
+    if (!c || !total_ms || batch <= 0 || iters <= 0) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t G = fheram_ctx::GLWE;
+    DevBuf da, db, dg;
+    HIPCHK(c, hipMalloc(&da.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&db.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&dg.p, fheram_ctx::GGSW * 4));
+    {   // synthetic normalised limbs
+        std::vector<int32_t> h(std::max((size_t)batch * G, fheram_ctx::GGSW));
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (int32_t)(x & 0x1FFFF) - 65536; }
+        HIPCHK(c, hipMemcpy(da.p, h.data(), (size_t)batch * G * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(dg.p, h.data(), fheram_ctx::GGSW * 4, hipMemcpyHostToDevice));
+    }
+    c->cur = c->stream;
+    launch_prepare(c, dg.p, c->d_prep, (int)(fheram_ctx::GGSW / N));
+    GlweRef ra = ref(da.p, 0, (long)G), rb = ref(db.p, 0, (long)G);
+    for (int i = 0; i < 3; i++) { launch_ep(c, ra, rb, c->d_prep, batch, 1); launch_ep(c, rb, ra, c->d_prep, batch, 1); }   // warm-up
+    HIPCHK(c, hipEventRecord(c->t0, c->stream));
+    for (int i = 0; i < iters; i++) launch_ep(c, (i & 1) ? rb : ra, (i & 1) ? ra : rb, c->d_prep, batch, 1);
+    HIPCHK(c, hipEventRecord(c->t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->t1));
+    HIPCHK(c, hipEventElapsedTime(total_ms, c->t0, c->t1));
+    HIPCHK(c, hipGetLastError());
+    return FHERAM_OK;
+}
 int fheram_device_info(const fheram_ctx* c, char* name, size_t name_len, int* cus) {
     if (!c) return FHERAM_ERR_INVALID_ARG;
     hipDeviceProp_t prop;

@@ -36,7 +36,10 @@ void launch_ep(fheram_ctx* c, GlweRef a, GlweRef res, const double* ggsw, int gx
         return;
     }
     if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_ext_product<3, 4, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
-    else hipLaunchKernelGGL((k_ext_product<3, 4, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+    else {
+        ProfScope pf(c, "ext_product_fused", (uint64_t)gx * gy);   // the dominant launch shape of its class, timed on its own
+        hipLaunchKernelGGL((k_ext_product<3, 4, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
+    }
 }
 template <int MODE, int SX, int SK, int SO>
 void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
@@ -50,7 +53,10 @@ void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
         return;
     }
     if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);
-    else hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ka);
+    else {
+        ProfScope pf(c, "keyswitch_fused", (uint64_t)gx * gy);     // the dominant launch shape (one workgroup per ciphertext)
+        hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ka);
+    }
 }
 void launch_copy(fheram_ctx* c, GlweRef src, GlweRef dst, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;

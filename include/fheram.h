@@ -217,6 +217,12 @@ int fheram_timer_end(fheram_ctx* ctx, float* elapsed_ms);
 int fheram_profile_enable(fheram_ctx* ctx, int on);
 int fheram_profile_get(fheram_ctx* ctx, const char* kernel_class, uint64_t* launches, uint64_t* blocks, double* total_ms);
 int fheram_profile_reset(fheram_ctx* ctx);
+/* BASELINE.json configs[1]: one GLWE x GGSW external product at N = 4096 on device-resident synthetic
+ * operands (normalised limbs; the work is data independent).  Runs `iters` launches of `batch` products
+ * back to back on the context's stream, each launch consuming the previous one's output (a dependent
+ * chain, as CoordinatePrepared::product is, coordinate_prepared.rs:147-161), and returns the HIP-event
+ * time of the whole chain in ms.  batch = 1 gives the latency of one product, batch >= #CUs the throughput. */
+int fheram_bench_external_product(fheram_ctx* ctx, int batch, int iters, float* total_ms);
 /* Device properties of the context's GPU (name, CU count) for the bench report. */
 int fheram_device_info(const fheram_ctx* ctx, char* name, size_t name_len, int* compute_units);
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Soak check of the HIP path (not collected by pytest): for a given number of seconds, random
+"""Soak check of the HIP path (tests/test_gpu_soak.py runs it for a bounded time in the driver's suite;
+longer runs by hand): for a given number of seconds, random
 ciphertext batches of the sizes that select each launch decomposition (fused, column split, limb
 parallel) go through trace steps, automorphisms, packing and external products, and a random sample of
 every result is compared bit for bit with the oracle; the same GPU call is also repeated and must
@@ -20,7 +21,7 @@ import pyoracle as po  # noqa: E402
 from _pkg import load_package  # noqa: E402
 
 
-def main(seconds=120):
+def main(seconds=120, seed=None):
     pkg = load_package()
     o = po.Oracle(po.OParams(max_addr=1 << 14))
     sk = o.secret_gen(1)
@@ -28,12 +29,16 @@ def main(seconds=120):
     okeys = o.keys_prepare(evk)
     keys = pkg.EvaluationKeysPrepared.from_dict(evk)
     ram = pkg.Ram.new_from_ram_params(4, [3, 3, 3, 3], 1 << 14)
-    rng = np.random.default_rng(int(time.time()))
+    seed = int(time.time()) if seed is None else seed
+    print("soak seed", seed, flush=True)
+    rng = np.random.default_rng(seed)
     glen = o.p.glwe_len
     t_end = time.time() + seconds
     rounds = checks = 0
     while time.time() < t_end:
-        batch = int(rng.choice([1, 3, 4, 16, 32, 64, 100, 128, 256, 300, 512]))
+        # batch sizes that select every launch decomposition: fine limb split (<= 10 ciphertexts), limb
+        # parallel (<= 32), split by column (<= 128), fused
+        batch = int(rng.choice([1, 3, 4, 8, 10, 11, 16, 32, 64, 100, 128, 256, 300, 512]))
         a = rng.integers(-(1 << 16), 1 << 16, size=(batch, glen), dtype=np.int64)
         sample = rng.choice(batch, size=min(batch, 3), replace=False)
         kind = int(rng.integers(0, 4))
@@ -76,6 +81,7 @@ def main(seconds=120):
         if rounds % 50 == 0:
             print(f"{rounds} rounds, {checks} oracle checks", flush=True)
     print(f"soak ok: {rounds} rounds, {checks} oracle checks in {seconds} s")
+    return rounds, checks
 
 
 if __name__ == "__main__":

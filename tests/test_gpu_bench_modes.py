@@ -1,0 +1,39 @@
+"""bench.py's other modes on the one GPU of the test box: the external-product microbenchmark
+(BASELINE.json configs[1]) and the row-sharded path with ONE rank under torch.distributed.run — RCCL
+all-gather / broadcast on device int32 buffers, ordered against the evaluator's stream with events
+(fheram_stream_signal / fheram_stream_wait), i.e. exactly the code N > 1 ranks run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_external_product_mode():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "ep", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = last_json(r.stdout)
+    assert out["value"] > 0 and 1.0 < out["latency_us_single_product"] < 200.0
+    assert 0.0 < out["roofline"]["frac"] < 1.0 and 0.0 < out["roofline_valu"]["frac"] < 1.0
+
+
+def test_bench_sharded_one_rank_rccl_device_buffers():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29553", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--mode", "sharded", "--log-max-addr", "14", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-kernel-timing"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = last_json(r.stdout)
+    assert out["mode"] == "sharded" and out["value"] > 0
