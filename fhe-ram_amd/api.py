@@ -78,6 +78,8 @@ _SYMBOLS = [
     ("fheram_stream_signal", C.c_int, [C.c_void_p, C.c_void_p]),
     ("fheram_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
     ("fheram_write_begin", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("fheram_device_malloc", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("fheram_device_free", C.c_int, [C.c_void_p, C.c_void_p]),
     ("fheram_read_partial", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     ("fheram_read_finish", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, I64P]),
     ("fheram_write_root", C.c_int, [C.c_void_p, I64P, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
@@ -594,6 +596,15 @@ class Ram:
     def stream_wait(self, hip_stream: int):
         """work this context enqueues later waits for everything enqueued on `hip_stream` so far"""
         self._chk(library().fheram_stream_wait(self._h, C.c_void_p(int(hip_stream))))
+
+    def device_malloc(self, n_bytes: int) -> int:
+        """device memory on this context's GPU for exchange buffers (pass (ptr, True) to the sharded ops)"""
+        out = C.c_void_p()
+        self._chk(library().fheram_device_malloc(self._h, n_bytes, C.byref(out)))
+        return int(out.value)
+
+    def device_free(self, ptr: int):
+        self._chk(library().fheram_device_free(self._h, C.c_void_p(int(ptr))))
 
     def write_shard(self, address: Address, keys: EvaluationKeysPrepared, ct_lo):
         self._use_keys(keys)

@@ -92,7 +92,8 @@ struct fheram_ctx {
     int32_t* d_w = nullptr;        // [ws]
     double* d_big = nullptr;       // [LIMB_SPLIT_MAX ciphertexts] un-normalised limbs of the limb-parallel path
     double* d_big2 = nullptr;      // same, for launches on the side stream
-    int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel path
+    int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel paths
+    int fine_split = 1;            // FHERAM_FINE_SPLIT=0 disables the fine limb split (one workgroup per input and output limb)
     int use_graph = 0;             // FHERAM_GRAPH=1: replay each op's launch sequence from a hipGraph (per address)
     int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo
     int32_t* d_gat[3] = {nullptr, nullptr, nullptr};   // [n_shards][ws] gathered partials + ping-pong (root)

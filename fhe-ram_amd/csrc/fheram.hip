@@ -92,6 +92,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     {
         const char* ls = getenv("FHERAM_LIMB_SPLIT");
         c->limb_split = (ls && ls[0] == '0') ? 0 : 1;
+        const char* fs = getenv("FHERAM_FINE_SPLIT");
+        c->fine_split = (fs && fs[0] == '0') ? 0 : 1;
         const char* gr = getenv("FHERAM_GRAPH");
         c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
         const char* e = getenv("FHERAM_NCO");
@@ -104,7 +106,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product<3, 4, 1>));
     LDSATTR((&k_ext_product<3, 4, 2>));
     LDSATTR((&k_ext_product<3, 4, 1, 1>));
-#define LDSATTR_KS(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>))
+    LDSATTR((&k_ext_product_fine<3, 4>));
+#define LDSATTR_KS(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);
     LDSATTR_KS(KS_TRACE, 3, 4, 3);
     LDSATTR_KS(KS_PAIR, 3, 4, 3);
@@ -374,6 +377,18 @@ int fheram_stream_wait(fheram_ctx* c, void* hip_stream) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventRecord(c->ev_xin, (hipStream_t)hip_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_xin, 0));
+    return FHERAM_OK;
+}
+int fheram_device_malloc(fheram_ctx* c, size_t bytes, void** out) {
+    if (!c || !out || bytes == 0) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(out, bytes));
+    return FHERAM_OK;
+}
+int fheram_device_free(fheram_ctx* c, void* ptr) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipFree(ptr));   // waits for outstanding work on the buffer
     return FHERAM_OK;
 }
 int fheram_write_begin(fheram_ctx* c, const fheram_addr* addr) {

@@ -657,10 +657,140 @@ __global__ __launch_bounds__(T, T / 256) void k_ntt_probe(const double* __restri
 }
 #endif
 
+// ---------------------------------------------------------------------------------------
+// Fine limb split, for the dependent chain at the end of every RAM op (word_size ciphertexts per round on a
+// 256-CU chip): one workgroup per (ciphertext, output column, output limb, INPUT limb).  The inverse
+// transform is linear, so  INTT(sum_r x^_r . K_r) = sum_r INTT(x^_r . K_r)  exactly (every partial product
+// is an integer below N*2^16*2^17 < p/2 and lifts to itself): each workgroup does ONE forward and ONE
+// inverse transform instead of SX + 1, and the normalisation pass adds the SX partial polynomials before it
+// walks the limbs.  Per coefficient the sums and the carry chain are the ones the fused kernel computes.
+//   grid (x, y, 2*SK*SX): z = ((co*SK + (SK-1-j))*SX + r);  partials at big + ct*BIG_STRIDE*SX + ((co*SK + j)*SX + r)*N
+// ---------------------------------------------------------------------------------------
+template <int MODE, int SX, int SK>
+__global__ __launch_bounds__(T, T / 256) void k_keyswitch_fine(KsArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    TwRegs twr;
+    twiddles_issue(twr, ka.tw, tid);
+    const int32_t* ap = at(ka.a);
+    const int32_t* bp = (MODE == KS_PAIR) ? at(ka.b) : nullptr;
+    constexpr int BODY_COL = (MODE == KS_TENSOR) ? 1 : 0;
+    constexpr bool PHI = (MODE != KS_TENSOR);
+    const int r = (int)blockIdx.z % SX, zz = (int)blockIdx.z / SX;
+    const int j = SK - 1 - zz % SK, co = zz / SK;
+    OpRegs g;
+    load_ops(g, ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
+    const int sidx0 = (tid * ka.ginv) & (2 * N - 1);
+    const int sstep = (T * ka.ginv) & (2 * N - 1);
+    int* mstage = reinterpret_cast<int*>(data);
+    double x[1][E];
+    if constexpr (PHI) {
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            int xm[SX];
+            load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
+            mstage[tid + T * k] = sel_limb(xm, r);
+        }
+        twiddles_commit(twr, tw, tid);   // its barrier also publishes the staged limb
+        int sidx = sidx0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            x[0][k] = (double)cneg(mstage[sidx & (N - 1)], sidx >= N);
+            sidx = (sidx + sstep) & (2 * N - 1);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            int xm[SX];
+            load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
+            x[0][k] = (double)sel_limb(xm, r);
+        }
+        twiddles_commit(twr, tw, tid);
+    }
+    ntt_fwd<1>(x, tw, data, tid);        // starts with a barrier: every gather of the staged limb is done
+    double acc[1][E];
+#pragma unroll
+    for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+    mac_regs(acc[0], x[0], g);
+    ntt_inv<1, false>(acc, tw, data, tid);
+    if (r == 0 && co == BODY_COL && j < SX) {   // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
+        int sidx = sidx0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            int xb[SX];
+            if constexpr (PHI) {
+                load_x<MODE, SX>(ka, ap, bp, 0, sidx & (N - 1), xb);
+                acc[0][k] += (double)cneg(sel_limb(xb, j), sidx >= N);
+                sidx = (sidx + sstep) & (2 * N - 1);
+            } else {
+                load_x<MODE, SX>(ka, ap, bp, 0, tid + T * k, xb);
+                acc[0][k] += (double)sel_limb(xb, j);
+            }
+        }
+    }
+    double* bgp = ka.big + big_ct() * SX + (long)((co * SK + j) * SX + r) * N;
+#pragma unroll
+    for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
+}
+
+// grid (x, y, 2*SG*2*SA): z = ((co*SG + (SG-1-j))*2 + cin)*SA + r;  partials at big + ct*BIG_STRIDE*2*SA + ((co*SG + j)*2*SA + cin*SA + r)*N
+template <int SA, int SG>
+__global__ __launch_bounds__(T, T / 256) void k_ext_product_fine(GlweRef a, const double* __restrict__ ggsw,
+                                                                 const double* __restrict__ tw_g, double* __restrict__ big) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    TwRegs twr;
+    twiddles_issue(twr, tw_g, tid);
+    const int32_t* ap = at(a);
+    const int r = (int)blockIdx.z % SA, z1 = (int)blockIdx.z / SA;
+    const int cin = z1 % 2, z2 = z1 / 2;
+    const int j = SG - 1 - z2 % SG, co = z2 / SG;
+    OpRegs g;
+    load_ops(g, ggsw + (long)(((2 * r + cin) * SG + j) * 2 + co) * N, tid);
+    double x[1][E];
+#pragma unroll
+    for (int k = 0; k < E; k++) x[0][k] = (double)ap[glwe_off(r, cin) + tid + T * k];
+    twiddles_commit(twr, tw, tid);
+    ntt_fwd<1>(x, tw, data, tid);
+    double acc[1][E];
+#pragma unroll
+    for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+    mac_regs(acc[0], x[0], g);
+    ntt_inv<1, false>(acc, tw, data, tid);
+    double* bp = big + big_ct() * (2 * SA) + (long)((co * SG + j) * 2 * SA + cin * SA + r) * N;
+#pragma unroll
+    for (int k = 0; k < E; k++) bp[tid + T * k] = acc[0][k];
+}
+// normalisation pass of k_ext_product_fine: one thread per coefficient, grid (x, y, 2 columns * N/256 slices)
+template <int SA, int SG>
+__global__ __launch_bounds__(256) void k_ext_product_fine_norm(GlweRef res, const double* __restrict__ big) {
+    constexpr int SLICES = N / 256, NP = 2 * SA;
+    const int co = (int)blockIdx.z / SLICES;
+    const int i = ((int)blockIdx.z % SLICES) * 256 + (int)threadIdx.x;
+    int32_t* rp = at(res);
+    const double* bp = big + big_ct() * NP + (long)co * SG * NP * N + i;
+    double carry = 0.0;
+#pragma unroll
+    for (int j = SG - 1; j >= 0; j--) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < NP; q++) v += bp[(long)(j * NP + q) * N];   // exact: integers below 2^47
+        v += carry;
+        const double cy = carry_of(v);
+        carry = cy;
+        if (j < SA) rp[glwe_off(j, co) + i] = (int)digit_of(v, cy);
+    }
+}
+
 // Normalisation / post-step pass of the limb-parallel path (STAGE 2 of k_keyswitch): one thread per
 // coefficient, grid (x, y, 2 columns * N/256 slices).  Same per-coefficient arithmetic as the
 // `emit` step of the fused kernel.
-template <int MODE, int SX, int SK, int SO>
+// NP > 1: the limbs arrive as NP partial polynomials each (k_keyswitch_fine) and are added first.
+template <int MODE, int SX, int SK, int SO, int NP = 1>
 __global__ __launch_bounds__(256) void k_keyswitch_norm(KsArgs ka) {
     constexpr int SLICES = N / 256;
     const int co = (int)blockIdx.z / SLICES;
@@ -669,10 +799,14 @@ __global__ __launch_bounds__(256) void k_keyswitch_norm(KsArgs ka) {
     const int32_t* ap = ra.p + (long)blockIdx.y * ra.sy + (long)blockIdx.x * ra.sx;
     const int32_t* bp = (MODE == KS_PAIR) ? rb.p + (long)blockIdx.y * rb.sy + (long)blockIdx.x * rb.sx : nullptr;
     int32_t* op = ro.p + (long)blockIdx.y * ro.sy + (long)blockIdx.x * ro.sx;
-    const double* bgp = ka.big + big_ct() + (long)co * SK * N + i;
+    const double* bgp = ka.big + big_ct() * NP + (long)co * SK * NP * N + i;
     double v_[SK];
 #pragma unroll
-    for (int j = 0; j < SK; j++) v_[j] = bgp[(long)j * N];
+    for (int j = 0; j < SK; j++) {
+        v_[j] = bgp[(long)(j * NP) * N];
+#pragma unroll
+        for (int q = 1; q < NP; q++) v_[j] += bgp[(long)(j * NP + q) * N];   // exact: integers below 2^47
+    }
     int xa[SX];
     if constexpr (MODE == KS_PAIR) load_pair_sum<SX>(ka, ap, bp, co, i, xa);
     else if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) load_x<MODE, SX>(ka, ap, bp, co, i, xa);

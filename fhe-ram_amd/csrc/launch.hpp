@@ -27,9 +27,19 @@ double* big_of(const fheram_ctx* c) { return c->cur == c->stream2 ? c->d_big2 : 
 bool use_limb_split(const fheram_ctx* c, int gx, int gy, int sk) {
     return c->limb_split && (long)gx * gy <= LIMB_SPLIT_MAX && (long)gx * gy * 2 * sk <= c->cus;
 }
+// Fine limb split (k_keyswitch_fine / k_ext_product_fine): wgs workgroups per ciphertext, one forward and one
+// inverse transform each, while the whole launch still fits the chip in one wave of workgroups.
+bool use_fine_split(const fheram_ctx* c, int gx, int gy, int wgs) {
+    return c->limb_split && c->fine_split && (long)gx * gy * wgs <= c->cus && (long)gx * gy * wgs * N * 8 <= (long)LIMB_SPLIT_MAX * BIG_STRIDE * 8;
+}
 void launch_ep(fheram_ctx* c, GlweRef a, GlweRef res, const double* ggsw, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "ext_product", (uint64_t)gx * gy);
+    if (use_fine_split(c, gx, gy, 2 * 4 * 2 * 3)) {
+        hipLaunchKernelGGL((k_ext_product_fine<3, 4>), dim3(gx, gy, 2 * 4 * 2 * 3), dim3(T), LDS_BYTES, c->cur, a, ggsw, c->d_tw, big_of(c));
+        hipLaunchKernelGGL((k_ext_product_fine_norm<3, 4>), dim3(gx, gy, 2 * (N / 256)), dim3(256), 0, c->cur, res, big_of(c));
+        return;
+    }
     if (use_limb_split(c, gx, gy, 4)) {
         hipLaunchKernelGGL((k_ext_product<3, 4, 1, 1>), dim3(gx, gy, 8), dim3(T), LDS_BYTES, c->cur, a, res, ggsw, c->d_tw, big_of(c));
         hipLaunchKernelGGL((k_ext_product<3, 4, 1, 2>), dim3(gx, gy, 2), dim3(T), 0, c->cur, a, res, ggsw, c->d_tw, big_of(c));
@@ -45,6 +55,13 @@ template <int MODE, int SX, int SK, int SO>
 void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
     ProfScope ps(c, "keyswitch", (uint64_t)gx * gy);
+    if (use_fine_split(c, gx, gy, 2 * SK * SX)) {
+        KsArgs kb = ka;
+        kb.big = big_of(c);
+        hipLaunchKernelGGL((k_keyswitch_fine<MODE, SX, SK>), dim3(gx, gy, 2 * SK * SX), dim3(T), LDS_BYTES, c->cur, kb);
+        hipLaunchKernelGGL((k_keyswitch_norm<MODE, SX, SK, SO, SX>), dim3(gx, gy, 2 * (N / 256)), dim3(256), 0, c->cur, kb);
+        return;
+    }
     if (use_limb_split(c, gx, gy, SK)) {
         KsArgs kb = ka;
         kb.big = big_of(c);

@@ -25,6 +25,9 @@ constexpr int N = 1 << LOGN;
 #ifndef FK_LOGE
 #define FK_LOGE 3
 #endif
+#ifndef FK_XCHG_REG
+#define FK_XCHG_REG 0   // 1: wave-local exchanges as register-lane transposes (DPP / v_permlane*_swap) instead of LDS
+#endif
 constexpr int LOGE = FK_LOGE;    // log2(coefficients per thread): 3 (512 threads) or 4 (256 threads)
 static_assert(LOGN % LOGE == 0, "radix must divide log N");
 constexpr int E = 1 << LOGE;     // coefficients per thread
@@ -102,8 +105,10 @@ __device__ __forceinline__ void lds_barrier() {
 // staged-limb gathers in the key-switch kernel; a barrier separates each of them from the writes
 // before it, and a barrier separates them from the writes after it (forward: right after the reads
 // of exchange 0; inverse: at the first LDS write of the next transform).
+template <int X, int B> __device__ __forceinline__ void exchange_reg(double (&x)[B][E], int tid);
 template <int X, int B>
 __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, int tid) {
+    if constexpr (FK_XCHG_REG && wave_local<X>()) { exchange_reg<X, B>(x, tid); return; }
     if constexpr (!wave_local<X>()) lds_barrier();   // cross-wave readers of the previous transform are done
 #pragma unroll
     for (int b = 0; b < B; b++)
@@ -120,6 +125,7 @@ __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, in
 }
 template <int X, int B>
 __device__ __forceinline__ void exchange_inv(double (&x)[B][E], double* data, int tid) {
+    if constexpr (FK_XCHG_REG && wave_local<X>()) { exchange_reg<X, B>(x, tid); return; }
     // no barrier before the write when everything since the fence at the start of ntt_inv was wave
     // local; a second cross-wave exchange (radix 4 only) must fence the readers of the one before it
     if constexpr (!wave_local<X>() && !wave_local<X + 1>()) lds_barrier();
@@ -132,6 +138,74 @@ __device__ __forceinline__ void exchange_inv(double (&x)[B][E], double* data, in
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) x[b][k] = data[b * LDS_DATA + lay<X>(pat<X>(tid, k))];
+}
+
+// ---- wave-local exchanges in registers (no LDS) -----------------------------------------------
+// Inside wave w the 512 elements i = 64a + 8b + c (a, b, c in 0..7) are held as
+//   pass 1: lane 8b + c, register a      pass 2: lane 8a + c, register b      pass 3: lane 8a + b, register c
+// so exchange 1 (pass 1 <-> 2) is an 8x8 transpose between the register index and lane bits 3..5, and
+// exchange 2 (pass 2 <-> 3) one between the register index and lane bits 0..2.  Each is three rounds of
+// "registers k and k + 2^t swap halves between lanes l and l ^ 2^(s+t)":
+//   lane bit 5 / 4 : v_permlane32_swap / v_permlane16_swap (gfx950), one instruction per dword pair;
+//   lane bit 3 / 2 : two DPP moves per dword pair (row_shr / row_shl by 8 / 4, the bank mask selecting
+//                    the half of each row that receives);
+//   lane bit 1 / 0 : DPP quad permutes + selects.
+// Selected with -DFK_XCHG_REG=1 (measured against the LDS form: make XREG=1, tools/ntt_bench.hip).
+template <int LANEBIT>
+__device__ __forceinline__ void lane_swap_u32(unsigned& a, unsigned& b, bool hi) {
+    // after: lanes with bit LANEBIT clear: b = a of lane ^ 2^LANEBIT;  lanes with it set: a = b of lane ^ 2^LANEBIT
+    if constexpr (LANEBIT == 5) {
+        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r[0]; b = r[1];
+    } else if constexpr (LANEBIT == 4) {
+        auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r[0]; b = r[1];
+    } else if constexpr (LANEBIT == 3) {
+        const unsigned na = __builtin_amdgcn_update_dpp(a, b, 0x118 /*row_shr:8*/, 0xF, 0xC, false);
+        const unsigned nb = __builtin_amdgcn_update_dpp(b, a, 0x108 /*row_shl:8*/, 0xF, 0x3, false);
+        a = na; b = nb;
+    } else if constexpr (LANEBIT == 2) {
+        const unsigned na = __builtin_amdgcn_update_dpp(a, b, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
+        const unsigned nb = __builtin_amdgcn_update_dpp(b, a, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
+        a = na; b = nb;
+    } else {
+        constexpr int ctrl = (LANEBIT == 1) ? 0x4E /*quad_perm:[2,3,0,1]*/ : 0xB1 /*quad_perm:[1,0,3,2]*/;
+        const unsigned pb = __builtin_amdgcn_update_dpp(0u, b, ctrl, 0xF, 0xF, false);
+        const unsigned pa = __builtin_amdgcn_update_dpp(0u, a, ctrl, 0xF, 0xF, false);
+        a = hi ? pb : a;
+        b = hi ? b : pa;
+    }
+}
+template <int LANEBIT>
+__device__ __forceinline__ void lane_swap(double& a, double& b, bool hi) {
+    unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a);
+    unsigned bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+    lane_swap_u32<LANEBIT>(al, bl, hi);
+    lane_swap_u32<LANEBIT>(ah, bh, hi);
+    a = __hiloint2double((int)ah, (int)al);
+    b = __hiloint2double((int)bh, (int)bl);
+}
+// 8x8 transpose between the register index and lane bits S0 .. S0+2
+template <int S0>
+__device__ __forceinline__ void transpose_reg_lane(double (&x)[E], int lane) {
+    static_assert(E == 8, "register transposes are written for radix 8");
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const bool hi = (lane >> (S0 + t)) & 1;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            if (k & (1 << t)) continue;
+            if (t == 0) lane_swap<S0 + 0>(x[k], x[k | 1], hi);
+            if (t == 1) lane_swap<S0 + 1>(x[k], x[k | 2], hi);
+            if (t == 2) lane_swap<S0 + 2>(x[k], x[k | 4], hi);
+        }
+    }
+}
+template <int X, int B>
+__device__ __forceinline__ void exchange_reg(double (&x)[B][E], int tid) {
+    static_assert(LOGE == 3 && (X == 1 || X == 2), "wave-local exchanges of the radix-8 transform");
+#pragma unroll
+    for (int b = 0; b < B; b++) transpose_reg_lane<(X == 1) ? 3 : 0>(x[b], tid & 63);
 }
 
 // Cooley-Tukey butterfly: (x, y) <- (x + w*y, x - w*y)

@@ -133,6 +133,11 @@ int fheram_ctx_create_sharded(const fheram_params* params, int device, int shard
  * s is a hipStream_t (NULL = the legacy default stream).  Host buffers (*_on_device = 0) need neither. */
 int fheram_stream_signal(fheram_ctx* ctx, void* hip_stream);
 int fheram_stream_wait(fheram_ctx* ctx, void* hip_stream);
+/* Exchange buffers on the context's device for a host that has no HIP binding of its own (hipMalloc /
+ * hipFree): `bytes` of device memory, e.g. n_shards * word_size * fheram_glwe_len * 4 for the gathered
+ * partials.  A host that already owns device memory (an RCCL / torch buffer) passes that instead. */
+int fheram_device_malloc(fheram_ctx* ctx, size_t bytes, void** out);
+int fheram_device_free(fheram_ctx* ctx, void* ptr);
 int fheram_shard_info(const fheram_ctx* ctx, int* shard, int* n_shards, size_t* local_rows);
 /* Every shard.  out: word_size partial GLWEs.  prepare_write != 0 keeps the rotated rows (ram.rs:502-504). */
 int fheram_read_partial(fheram_ctx* ctx, const fheram_addr* addr, int prepare_write, void* out, int out_on_device);

@@ -80,27 +80,27 @@ def test_sharded_flow_matches_committed_digests(po, n_shards, max_addr, device_b
         r.load_encrypted(inp["rows"][:, g::G])
 
     if device_buffers:
-        import torch
-        parts = torch.zeros((G, ws, glen), dtype=torch.int32, device="cuda")
-        ctlo = torch.zeros((ws, glen), dtype=torch.int32, device="cuda")
-        xs = torch.cuda.current_stream().cuda_stream        # stands for the collective's stream
-        torch.cuda.synchronize()
+        # exchange buffers in device memory (int32 GLWEs); the legacy default stream stands for the collective's
+        # stream: the contexts' streams are non-blocking, so only the event hand-over orders them against it
+        parts_ptr = shards[0].device_malloc(G * ws * glen * 4)
+        ctlo_ptr = shards[0].device_malloc(ws * glen * 4)
+        xs = 0
 
         def read(prepare_write):
             for g, (r, a) in enumerate(zip(shards, addrs)):
-                r.read_partial(a, keys, prepare_write, out=(parts[g].data_ptr(), True))
+                r.read_partial(a, keys, prepare_write, out=(parts_ptr + g * ws * glen * 4, True))
                 r.stream_signal(xs)                         # "all-gather" = the shards wrote their slices in place
             shards[0].stream_wait(xs)
-            return shards[0].read_finish(addrs[0], keys, (parts.data_ptr(), True), prepare_write)
+            return shards[0].read_finish(addrs[0], keys, (parts_ptr, True), prepare_write)
 
         def write(w):
             for r, a in zip(shards, addrs):
                 r.write_begin(a, keys)
-            shards[0].write_root(w, addrs[0], keys, out=(ctlo.data_ptr(), True))
+            shards[0].write_root(w, addrs[0], keys, out=(ctlo_ptr, True))
             shards[0].stream_signal(xs)                     # "broadcast"
             for r, a in zip(shards, addrs):
                 r.stream_wait(xs)
-                r.write_shard(a, keys, (ctlo.data_ptr(), True))
+                r.write_shard(a, keys, (ctlo_ptr, True))
     else:
         def read(prepare_write):
             partials = np.stack([r.read_partial(a, keys, prepare_write) for r, a in zip(shards, addrs)])
@@ -123,3 +123,8 @@ def test_sharded_flow_matches_committed_digests(po, n_shards, max_addr, device_b
     out["rows_after_write"] = sha(rows())
     out["readback"] = sha(read(False))
     assert out == d["outputs"]
+    if device_buffers:
+        for r in shards:
+            r.sync()
+        shards[0].device_free(parts_ptr)
+        shards[0].device_free(ctlo_ptr)
