@@ -590,7 +590,7 @@ int fheram_debug_ntt_probe(fheram_ctx* c, int blocks) {
 int fheram_debug_stamps(fheram_ctx* c, unsigned long long* out, int n) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n > 64 ? 64 : n)) == hipSuccess ? 0 : 7;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n > 192 ? 192 : n)) == hipSuccess ? 0 : 7;
 }
 #endif
 int fheram_bench_external_product(fheram_ctx* c, int batch, int iters, float* total_ms) {

@@ -21,7 +21,7 @@ namespace fk {
 // Diagnostic build only (-DFK_STAMP): s_memtime stamps of workgroup (0,0,0), lane 0, written to a
 // buffer nothing else reads.  Never compiled into the shipped library.
 #ifdef FK_STAMP
-__device__ unsigned long long g_stamps[64];
+__device__ unsigned long long g_stamps[192];
 #define STAMP(i)                                                                                   \
     do {                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -32,8 +32,19 @@ __device__ unsigned long long g_stamps[64];
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
+#define STAMPZ(i)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (blockIdx.z == 0 || blockIdx.z == 3)) { \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            g_stamps[(blockIdx.z == 0 ? 128 : 144) + (i)] = t_;                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMPZ(i) do { } while (0)
 #endif
 
 struct GlweRef {   // p + y*sy + x*sx  (int32 elements)
@@ -124,6 +135,9 @@ __device__ __forceinline__ void mac_regs(double (&acc)[E], const double (&x)[E],
 #define FK_BI 1
 #endif
 constexpr int BF = FK_BF, BI = FK_BI;
+#ifndef FK_EARLY_FETCH
+#define FK_EARLY_FETCH 0
+#endif
 static_assert(BF <= BMAX && BI <= BMAX, "LDS holds BMAX exchange buffers");
 
 // forward transform of S polynomials, BF at a time
@@ -278,8 +292,12 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
                 if (b > 0) ep_fetch0<SA, SG>(g, ggsw, j - b, co, tid);
                 ep_mac<SA, SG>(acc[b], x0, x1, g, ggsw, j - b, co, j - b - 1, tid);
             }
+            if constexpr (FK_EARLY_FETCH == 1) {
+                if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             ntt_inv<BI, !DB>(acc, tw, data + (DB ? (it++ & 1) * BI * LDS_DATA : 0), tid);
-            if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid);   // overlaps the normalisation step
+            if constexpr (FK_EARLY_FETCH == 0) { if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid); }   // overlaps the normalisation step
 #pragma unroll
             for (int b = 0; b < BI; b++) emit(acc[b], j - b);
         }
@@ -362,6 +380,55 @@ __device__ __forceinline__ void load_pair_sum(const KsArgs& ka, const int32_t* a
     rsh1_coeff<SX>(v, x);
 }
 
+// load_x in two halves, so that a kernel can issue the loads of several coefficients / columns before it
+// waits for any of them: raw limbs of a (and b) at the source coefficient, then the pre-step in registers
+template <int MODE, int SX>
+struct RawX { int a[SX]; int b[SX]; bool neg; };
+template <int MODE, int SX>
+__device__ __forceinline__ void load_raw(const KsArgs& ka, const int32_t* ap, const int32_t* bp, int col, int i, RawX<MODE, SX>& r) {
+    int src = i;
+    r.neg = false;
+    if constexpr (MODE == KS_TRACE) rot_src(i, -(ka.rot_base + (int)blockIdx.x * ka.rot_mul), src, r.neg);
+    if constexpr (MODE == KS_PAIR) rot_src(i, -ka.t, src, r.neg);
+#pragma unroll
+    for (int j = 0; j < SX; j++) {
+        r.a[j] = ap[glwe_off(j, col) + src];
+        if constexpr (MODE == KS_PAIR) r.b[j] = bp[glwe_off(j, col) + i];
+    }
+}
+template <int MODE, int SX>
+__device__ __forceinline__ void pre_step(const RawX<MODE, SX>& r, int (&x)[SX]) {
+    if constexpr (MODE == KS_TRACE) {
+        int v[SX];
+#pragma unroll
+        for (int j = 0; j < SX; j++) v[j] = cneg(r.a[j], r.neg);
+        rsh1_coeff<SX>(v, x);
+    } else if constexpr (MODE == KS_PAIR) {
+        int v[SX];
+#pragma unroll
+        for (int j = 0; j < SX; j++) v[j] = cneg(r.a[j], r.neg) - r.b[j];
+        rsh1_coeff<SX>(v, x);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SX; j++) x[j] = r.a[j];
+    }
+}
+
+// KS_PAIR: rsh1(rot(a,-t) + b) from the raw limbs
+template <int MODE, int SX>
+__device__ __forceinline__ void pair_sum_raw(const RawX<MODE, SX>& r, int (&x)[SX]) {
+    int v[SX];
+#pragma unroll
+    for (int j = 0; j < SX; j++) v[j] = cneg(r.a[j], r.neg) + r.b[j];
+    rsh1_coeff<SX>(v, x);
+}
+// three limbs in [-2^16, 2^16] as 18-bit fields of one 64-bit word
+__device__ __forceinline__ unsigned long long pack18(const int (&v)[3]) {
+    return (unsigned long long)(unsigned)(v[0] + (1 << 17)) | ((unsigned long long)(unsigned)(v[1] + (1 << 17)) << 18) |
+           ((unsigned long long)(unsigned)(v[2] + (1 << 17)) << 36);
+}
+__device__ __forceinline__ int unpack18(unsigned long long w, int j) { return (int)((w >> (18 * j)) & 0x3FFFF) - (1 << 17); }
+
 __device__ __forceinline__ int sel_limb(const int (&x)[3], int j) { return j == 0 ? x[0] : (j == 1 ? x[1] : x[2]); }
 __device__ __forceinline__ int sel_limb(const int (&x)[4], int j) { return j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : x[3])); }
 
@@ -417,9 +484,74 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     const int sidx0 = (tid * ka.ginv) & (2 * N - 1);
     const int sstep = (T * ka.ginv) & (2 * N - 1);
 
+    // FAST path (the automorphism family on 3-limb ciphertexts, fused stage): BOTH columns of the input are
+    // requested at the very start, pre-stepped once and kept as packed words (three 18-bit fields, 2 VGPRs per
+    // coefficient): pa0 / pa1 = what the post-step adds to column 0 / 1 (x itself; KS_PAIR: the pair sum),
+    // pbody = x column 0 for the body staging.  Without this every column began with a global round trip of
+    // its own (4.3 + 2.1 us of a 50 us kernel, profiles/r02_stamps_keyswitch.txt).
+    // (not for the fused two-column KS_PAIR: three packed operands per coefficient do not fit its registers)
+    constexpr bool FAST = PHI && SX == 3 && STAGE == 0 && !(MODE == KS_PAIR && NCO == 2);
+    constexpr bool HAS_XA = (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG || MODE == KS_PAIR);
+    unsigned long long pa0[E], pa1[E], pbody[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) pa0[k] = pa1[k] = pbody[k] = 0;
+
     // Phase 1: mask column of x, all limbs, mapped through phi_g and transformed
     double xh[SX][E];
-    if constexpr (STAGE != 2) {
+    if constexpr (FAST) {
+        constexpr int SXF = 3;
+        const bool need0 = (NCO == 2) || (co0 == 0);     // column 0: the body, and the post-step operand of column 0
+        RawX<MODE, SXF> rm[E], rb[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) load_raw<MODE, SXF>(ka, ap, bp, 1, tid + T * k, rm[k]);
+        if (need0) {
+#pragma unroll
+            for (int k = 0; k < E; k++) load_raw<MODE, SXF>(ka, ap, bp, 0, tid + T * k, rb[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            int xm[SXF];
+            pre_step<MODE, SXF>(rm[k], xm);
+#pragma unroll
+            for (int r = 0; r < SXF; r++) mstage[r * N + tid + T * k] = xm[r];
+            if constexpr (MODE == KS_PAIR) {
+                int sm[SXF];
+                pair_sum_raw<MODE, SXF>(rm[k], sm);
+                pa1[k] = pack18(sm);
+            } else if constexpr (HAS_XA) {
+                pa1[k] = pack18(xm);
+            }
+        }
+        if (need0) {
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                int x0[SXF];
+                pre_step<MODE, SXF>(rb[k], x0);
+                pbody[k] = pack18(x0);
+                if constexpr (MODE == KS_PAIR) {
+                    int sm[SXF];
+                    pair_sum_raw<MODE, SXF>(rb[k], sm);
+                    pa0[k] = pack18(sm);
+                } else if constexpr (HAS_XA) {
+                    pa0[k] = pbody[k];
+                }
+            }
+        }
+        twiddles_commit(twr, tw, tid);   // its barrier also publishes the staged limbs
+        int sidx = sidx0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const bool ng = sidx >= N;
+            const int s_ = sidx & (N - 1);
+#pragma unroll
+            for (int r = 0; r < SXF; r++) xh[r][k] = (double)cneg(mstage[r * N + s_], ng);
+            sidx = (sidx + sstep) & (2 * N - 1);
+        }
+        STAMP(2);
+        fwd_all<SX>(xh, tw, data, tid);
+        STAMP(3);
+    } else if constexpr (STAGE != 2) {
         if constexpr (PHI) {
 #pragma unroll
             for (int k = 0; k < E; k++) {
@@ -458,9 +590,21 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll 1
     for (int c = 0; c < NCOL; c++) {
         const int co = co0 + c;
+        STAMP(6 + 24 * c);
         // per-coefficient limbs needed by the post-step of this column
         int xa[E][SX];   // KS_TRACE/ADD/SUBNEG: x column co;  KS_PAIR: rsh1(rot(a,-t)+b) column co
         int xb[E][SX];   // KS_TENSOR: body limbs of x (column 0), added to column 1
+        unsigned long long px[E];   // FAST: packed post-step operand of this column
+        if constexpr (FAST) {
+#pragma unroll
+            for (int k = 0; k < E; k++) px[k] = (co == 0) ? pa0[k] : pa1[k];
+            if (co == BODY_COL) {   // stage the body limbs of x (natural order) for the gathers of add_body
+                lds_barrier();      // slower waves may still be inside the wave-local exchanges of the forward transforms
+#pragma unroll
+                for (int k = 0; k < E; k++) bstage[tid + T * k] = pbody[k];
+                // published by the barriers of the first inverse transform, which precede every gather
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const int i = tid + T * k;
@@ -468,7 +612,8 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             else if constexpr (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG) load_x<MODE, SX>(ka, ap, bp, co, i, xa[k]);
             else if constexpr (MODE == KS_TENSOR) load_x<MODE, SX>(ka, ap, bp, 0, i, xb[k]);
         }
-        if constexpr (PHI) {
+        }
+        if constexpr (PHI && !FAST) {
             if (co == BODY_COL) {   // stage the body limbs of x (natural order) for the gathers of add_body
                 lds_barrier();      // slower waves may still be inside the wave-local exchanges of the forward transforms
 #pragma unroll
@@ -529,8 +674,13 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             for (int k = 0; k < E; k++) {
                 const int i = tid + T * k;
                 double v = acc[k];
-                if constexpr (MODE == KS_TRACE || MODE == KS_ADD) { if (j < SX) v += (double)sel_limb(xa[k], j); }
-                if constexpr (MODE == KS_SUBNEG) v = (j < SX ? (double)sel_limb(xa[k], j) : 0.0) - v;
+                int xl = 0;   // limb j of the post-step operand at this coefficient
+                if constexpr (HAS_XA) {
+                    if constexpr (FAST) xl = unpack18(px[k], j < SX ? j : 0);
+                    else xl = sel_limb(xa[k], j);
+                }
+                if constexpr (MODE == KS_TRACE || MODE == KS_ADD) { if (j < SX) v += (double)xl; }
+                if constexpr (MODE == KS_SUBNEG) v = (j < SX ? (double)xl : 0.0) - v;
                 v += carry[k];
                 const double cy = carry_of(v);
                 carry[k] = cy;
@@ -538,7 +688,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
                     const double d = digit_of(v, cy);
                     if constexpr (MODE == KS_PAIR) {
                         // a <- normalize(rsh1(a*X^-t + b) - tmp); a <- a * X^t
-                        const double v2 = (double)sel_limb(xa[k], j) - d + carry2[k];
+                        const double v2 = (double)xl - d + carry2[k];
                         const double cy2 = carry_of(v2);
                         carry2[k] = cy2;
                         int dst = i + ka.t;
@@ -565,28 +715,32 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             return;
         }
         constexpr int REM = SK % KBI;
-        STAMP(4);
+        STAMP(4 + 24 * c);
         fetch(SK - 1);
 #pragma unroll 1
         for (int j = SK - 1; j >= KBI - 1 + REM; j -= KBI) {
             double acc[KBI][E];
-            STAMP(8 + 4 * (SK - 1 - j));
+            STAMP(8 + 4 * (SK - 1 - j) + 24 * c);
 #pragma unroll
             for (int b = 0; b < KBI; b++) {
                 if (b > 0) fetch(j - b);
                 mac(acc[b], j - b - 1);
             }
-            STAMP(9 + 4 * (SK - 1 - j));
+            STAMP(9 + 4 * (SK - 1 - j) + 24 * c);
+            if constexpr (FK_EARLY_FETCH == 1) {   // operands of the next limb requested BEFORE the transform: 48 more live registers across it
+                if (j - KBI >= 0) fetch(j - KBI);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             ntt_inv<KBI, !DB>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
-            if (j - KBI >= 0) fetch(j - KBI);   // next limb's operands: their latency overlaps the post-step
-            STAMP(10 + 4 * (SK - 1 - j));
+            if constexpr (FK_EARLY_FETCH == 0) { if (j - KBI >= 0) fetch(j - KBI); }   // (FK_EARLY_FETCH == 2: timing diagnostic, operands never refetched, results wrong)   // next limb's operands: their latency overlaps the post-step
+            STAMP(10 + 4 * (SK - 1 - j) + 24 * c);
 #pragma unroll
             for (int b = 0; b < KBI; b++) add_body(acc[b], j - b);
-            STAMP(11 + 4 * (SK - 1 - j));
+            STAMP(11 + 4 * (SK - 1 - j) + 24 * c);
 #pragma unroll
             for (int b = 0; b < KBI; b++) emit(acc[b], j - b);
         }
-        STAMP(5);
+        STAMP(5 + 24 * c);
         if constexpr (REM == 1) {
             double acc[1][E];
             mac(acc[0], -1);
@@ -672,6 +826,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_fine(KsArgs ka) {
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = threadIdx.x;
+    STAMPZ(0);
     TwRegs twr;
     twiddles_issue(twr, ka.tw, tid);
     const int32_t* ap = at(ka.a);
@@ -685,54 +840,78 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_fine(KsArgs ka) {
     const int sidx0 = (tid * ka.ginv) & (2 * N - 1);
     const int sstep = (T * ka.ginv) & (2 * N - 1);
     int* mstage = reinterpret_cast<int*>(data);
+    // vec_znx_big_add_small_inplace of body limb j, seen through phi_g: ONE workgroup per (column, limb) adds it.
+    // Like the mask limb it is loaded coalesced, staged in LDS and gathered with the odd stride g^-1.  ALL global
+    // loads of the workgroup are issued before the first one is waited for: the inputs were written by the
+    // previous kernel on other XCDs and every dependent round trip costs a fabric latency (2-3 us).
+    const bool adds_body = (r == 0 && co == BODY_COL && j < SX);
+    int* bstage = mstage + N;
+    int bodyv[E];
     double x[1][E];
+    RawX<MODE, SX> rm[E], rb[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) load_raw<MODE, SX>(ka, ap, bp, 1, tid + T * k, rm[k]);
+    if (adds_body) {
+#pragma unroll
+        for (int k = 0; k < E; k++) load_raw<MODE, SX>(ka, ap, bp, 0, tid + T * k, rb[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (PHI) {
 #pragma unroll
         for (int k = 0; k < E; k++) {
             int xm[SX];
-            load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
+            pre_step<MODE, SX>(rm[k], xm);
             mstage[tid + T * k] = sel_limb(xm, r);
         }
-        twiddles_commit(twr, tw, tid);   // its barrier also publishes the staged limb
+        if (adds_body) {
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                int xb[SX];
+                pre_step<MODE, SX>(rb[k], xb);
+                bstage[tid + T * k] = sel_limb(xb, j);
+            }
+        }
+        STAMPZ(1);
+        twiddles_commit(twr, tw, tid);   // its barrier also publishes the staged limbs
+        STAMPZ(2);
         int sidx = sidx0;
 #pragma unroll
         for (int k = 0; k < E; k++) {
             x[0][k] = (double)cneg(mstage[sidx & (N - 1)], sidx >= N);
+            bodyv[k] = adds_body ? cneg(bstage[sidx & (N - 1)], sidx >= N) : 0;
             sidx = (sidx + sstep) & (2 * N - 1);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < E; k++) {
             int xm[SX];
-            load_x<MODE, SX>(ka, ap, bp, 1, tid + T * k, xm);
+            pre_step<MODE, SX>(rm[k], xm);
             x[0][k] = (double)sel_limb(xm, r);
+            bodyv[k] = 0;
+            if (adds_body) {
+                int xb[SX];
+                pre_step<MODE, SX>(rb[k], xb);
+                bodyv[k] = sel_limb(xb, j);
+            }
         }
         twiddles_commit(twr, tw, tid);
     }
+    STAMPZ(3);
     ntt_fwd<1>(x, tw, data, tid);        // starts with a barrier: every gather of the staged limb is done
+    STAMPZ(4);
     double acc[1][E];
 #pragma unroll
     for (int k = 0; k < E; k++) acc[0][k] = 0.0;
     mac_regs(acc[0], x[0], g);
+    STAMPZ(5);
     ntt_inv<1, false>(acc, tw, data, tid);
-    if (r == 0 && co == BODY_COL && j < SX) {   // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
-        int sidx = sidx0;
+    STAMPZ(6);
 #pragma unroll
-        for (int k = 0; k < E; k++) {
-            int xb[SX];
-            if constexpr (PHI) {
-                load_x<MODE, SX>(ka, ap, bp, 0, sidx & (N - 1), xb);
-                acc[0][k] += (double)cneg(sel_limb(xb, j), sidx >= N);
-                sidx = (sidx + sstep) & (2 * N - 1);
-            } else {
-                load_x<MODE, SX>(ka, ap, bp, 0, tid + T * k, xb);
-                acc[0][k] += (double)sel_limb(xb, j);
-            }
-        }
-    }
+    for (int k = 0; k < E; k++) acc[0][k] += (double)bodyv[k];
     double* bgp = ka.big + big_ct() * SX + (long)((co * SK + j) * SX + r) * N;
 #pragma unroll
     for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
+    STAMPZ(7);
 }
 
 // grid (x, y, 2*SG*2*SA): z = ((co*SG + (SG-1-j))*2 + cin)*SA + r;  partials at big + ct*BIG_STRIDE*2*SA + ((co*SG + j)*2*SA + cin*SA + r)*N

@@ -15,18 +15,21 @@ def probe(batch, label):
     a = synth((batch, ram.params.glwe_len()))
     for _ in range(3):
         ram.glwe_trace(keys, 3, 4, a)      # one trace step = one k_keyswitch<KS_TRACE> launch
-    st = (C.c_uint64 * 64)()
-    L.fheram_debug_stamps(ram._h, st, 64)
+    st = (C.c_uint64 * 192)()
+    L.fheram_debug_stamps(ram._h, st, 192)
     s = [int(x) for x in st]
     t0 = s[0]
     print(f"== {label}: batch {batch}")
-    names = {0: "start", 1: "twiddles in LDS", 2: "x loaded (+rsh)", 3: "forward NTT x3 done", 4: "post-step limbs loaded", 5: "column done"}
-    for i in (0, 1, 2, 3, 4):
-        print(f"  {names[i]:28s} {s[i]-t0:8d} cyc")
-    for q in range(4):
-        b = 8 + 4 * q
-        print(f"  limb {3-q}: mac {s[b+1]-s[b]:6d}  inv-ntt {s[b+2]-s[b+1]:6d}  body add      {s[b+3]-s[b+2]:6d}  | start {s[b]-t0}")
-    print(f"  {names[5]:28s} {s[5]-t0:8d} cyc")
+    names = {0: "start", 1: "twiddles issued", 2: "x loaded (+rsh), staged, gathered", 3: "forward NTT x3 done"}
+    for i in (0, 1, 2, 3):
+        print(f"  {names[i]:36s} {s[i]-t0:8d} ticks")
+    for c in (0, 1):
+        o = 24 * c
+        print(f"  column {c}: loop top {s[6+o]-t0}, post-step limbs loaded / body staged {s[4+o]-t0} (+{s[4+o]-s[6+o]})")
+        for q in range(4):
+            b = 8 + 4 * q + o
+            nxt = s[b + 4] if q < 3 else s[5 + o]
+            print(f"    limb {3-q}: start {s[b]-t0:7d}  mac {s[b+1]-s[b]:6d}  inv-ntt {s[b+2]-s[b+1]:6d}  body add {s[b+3]-s[b+2]:6d}  emit(+fetch wait) {nxt-s[b+3]:6d}")
+        print(f"    column done {s[5+o]-t0}")
 os.environ.setdefault("FHERAM_NCO", "0")
-probe(4, "tail (NCO=1, 8 workgroups)")
 probe(256, "full (NCO=2, 256 workgroups)")
