@@ -93,6 +93,7 @@ struct fheram_ctx {
     double* d_big = nullptr;       // [LIMB_SPLIT_MAX ciphertexts] un-normalised limbs of the limb-parallel path
     double* d_big2 = nullptr;      // same, for launches on the side stream
     int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel paths
+    int chain = 1;                 // FHERAM_CHAIN=0: one launch per step instead of one launch per dependent chain of fused steps
     int fine_split = 1;            // FHERAM_FINE_SPLIT=0 disables the fine limb split (one workgroup per input and output limb)
     int use_graph = 0;             // FHERAM_GRAPH=1: replay each op's launch sequence from a hipGraph (per address)
     int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo
@@ -152,10 +153,12 @@ hipEvent_t get_event(fheram_ctx* c) {
 }
 struct ProfScope {
     fheram_ctx* c; ProfCls* cls = nullptr; hipEvent_t a = nullptr;
-    ProfScope(fheram_ctx* c_, const char* name, uint64_t blocks) : c(c_) {
+    // steps: ciphertext-operation rounds inside the launch (a chain kernel runs several): `launches` counts rounds,
+    // so that ms / launches stays the time of ONE round over `blocks / launches` ciphertexts
+    ProfScope(fheram_ctx* c_, const char* name, uint64_t blocks, int steps = 1) : c(c_) {
         if (!c->profile) return;
         cls = &c->prof[name];
-        cls->launches++; cls->blocks += blocks;
+        cls->launches += steps; cls->blocks += blocks * steps;
         a = get_event(c);
         hipEventRecord(a, c->cur);
     }

@@ -94,6 +94,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->limb_split = (ls && ls[0] == '0') ? 0 : 1;
         const char* fs = getenv("FHERAM_FINE_SPLIT");
         c->fine_split = (fs && fs[0] == '0') ? 0 : 1;
+        const char* ch = getenv("FHERAM_CHAIN");
+        c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* gr = getenv("FHERAM_GRAPH");
         c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
         const char* e = getenv("FHERAM_NCO");
@@ -107,6 +109,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product<3, 4, 2>));
     LDSATTR((&k_ext_product<3, 4, 1, 1>));
     LDSATTR((&k_ext_product_fine<3, 4>));
+    LDSATTR((&k_ext_product_chain<3, 4>));
+    LDSATTR((&k_keyswitch_chain<3, 4, 3>));
 #define LDSATTR_KS(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);
     LDSATTR_KS(KS_TRACE, 3, 4, 3);

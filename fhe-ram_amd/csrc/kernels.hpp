@@ -185,11 +185,12 @@ __device__ __forceinline__ void ep_fetch0(OpRegs (&g)[SA], const double* __restr
 constexpr int BIG_STRIDE = 2 * 5 * N;   // doubles of `big` per ciphertext: [column][limb <= 5][N]
 __device__ __forceinline__ long big_ct() { return ((long)blockIdx.y * gridDim.x + blockIdx.x) * BIG_STRIDE; }
 
+// The body is a device function so that a chain of products on the same ciphertext can run inside ONE launch
+// (k_ext_product_chain): load_tw = false skips the twiddle table (already in LDS from the previous step).
 template <int SA, int SG, int NCO, int STAGE = 0>
-__global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
-                                                            const double* __restrict__ tw_g, double* __restrict__ big) {
+__device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
+                                       const double* __restrict__ tw_g, double* __restrict__ big, double* lds, bool load_tw, const int tid) {
     if constexpr (STAGE == 2) {
-        const int tid = threadIdx.x;
         const int co = (int)blockIdx.z;
         int32_t* rp = at(res);
         const double* bp = big + big_ct() + (long)co * SG * N;
@@ -208,12 +209,10 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
         }
         return;
     }
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
-    const int tid = threadIdx.x;
     TwRegs twr;
-    twiddles_issue(twr, tw_g, tid);
+    if (load_tw) twiddles_issue(twr, tw_g, tid);
     const int32_t* ap = at(a);
     int32_t* rp = at(res);
     const int co0 = (NCO == 1) ? (int)blockIdx.z : 0;
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
         for (int r = 0; r < SA; r++)
 #pragma unroll
             for (int k = 0; k < E; k++) xi[r][k] = ap[glwe_off(r, 0) + tid + T * k];
-        twiddles_commit(twr, tw, tid);
+        if (load_tw) twiddles_commit(twr, tw, tid);
 #pragma unroll
         for (int r = 0; r < SA; r++)
 #pragma unroll
@@ -309,6 +308,40 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
             ntt_inv<1, !DB>(acc, tw, data + (DB ? (it++ & 1) * BI * LDS_DATA : 0), tid);
             emit(acc[0], 0);
         }
+    }
+}
+
+template <int SA, int SG, int NCO, int STAGE = 0>
+__global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
+                                                            const double* __restrict__ tw_g, double* __restrict__ big) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    ep_run<SA, SG, NCO, STAGE>(a, res, ggsw, tw_g, big, lds, true, (int)threadIdx.x);
+}
+// CoordinatePrepared::product(_inplace) (coordinate_prepared.rs:147-177) as ONE launch: the n external products
+// of a coordinate's digits on the same ciphertext, one workgroup per ciphertext.  Step i reads what step
+// i - 1 wrote (the workgroup's own slots of the two ping-pong buffers: no other workgroup touches them), so
+// the steps need no device-wide synchronisation — what a sequence of launches pays per step (kernel drain and
+// ramp, kernel arguments, the twiddle table, a cold first load: 5-6 us of 55) is paid once.
+constexpr int CHAIN_MAX = 12;
+struct EpChainArgs {
+    GlweRef src, buf[2];             // step i writes buf[i & 1] (buf[0] must not be src)
+    const double* ggsw[CHAIN_MAX];   // prepared digits
+    const double* tw;
+    int n;
+};
+template <int SA, int SG>
+__global__ __launch_bounds__(T, T / 256) void k_ext_product_chain(EpChainArgs ca) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    GlweRef in = ca.src;
+#pragma unroll 1
+    for (int i = 0; i < ca.n; i++) {
+        const GlweRef out = ca.buf[i & 1];
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));   // per-step copy the optimiser cannot see through: keeps it from hoisting every
+                                        // thread-index-derived address out of the step loop (56 spilled registers)
+        ep_run<SA, SG, 2, 0>(in, out, ca.ggsw[i], ca.tw, nullptr, lds, i == 0, tid);
+        __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
+        in = out;
     }
 }
 
@@ -443,14 +476,12 @@ __device__ __forceinline__ int sel_limb(const int (&x)[4], int j) { return j == 
 // of small integers per ciphertext instead of one permutation of every output limb.
 // NCO as in k_ext_product.  out must not alias a or b.
 template <int MODE, int SX, int SK, int SO, int NCO, int STAGE = 0>
-__global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_tw, const int tid) {
     double* tw = lds;
     double* data = lds + LDS_TW;
-    const int tid = threadIdx.x;
     STAMP(0);
     TwRegs twr;
-    twiddles_issue(twr, ka.tw, tid);
+    if (load_tw) twiddles_issue(twr, ka.tw, tid);
     STAMP(1);
     const int32_t* ap = at(ka.a);
     const int32_t* bp = (MODE == KS_PAIR) ? at(ka.b) : nullptr;
@@ -538,7 +569,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
                 }
             }
         }
-        twiddles_commit(twr, tw, tid);   // its barrier also publishes the staged limbs
+        if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();   // its barrier also publishes the staged limbs
         int sidx = sidx0;
 #pragma unroll
         for (int k = 0; k < E; k++) {
@@ -560,7 +591,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll
                 for (int r = 0; r < SX; r++) mstage[r * N + tid + T * k] = xm[r];
             }
-            twiddles_commit(twr, tw, tid);   // its barrier also publishes the staged limbs
+            if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();   // its barrier also publishes the staged limbs
             int sidx = sidx0;
 #pragma unroll
             for (int k = 0; k < E; k++) {
@@ -580,7 +611,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
 #pragma unroll
                 for (int r = 0; r < SX; r++) xh[r][k] = (double)xm[r];
             }
-            twiddles_commit(twr, tw, tid);
+            if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();
         }
         STAMP(2);
         fwd_all<SX>(xh, tw, data, tid);
@@ -748,6 +779,42 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
             add_body(acc[0], 0);
             emit(acc[0], 0);
         }
+    }
+}
+
+template <int MODE, int SX, int SK, int SO, int NCO, int STAGE = 0>
+__global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    ks_run<MODE, SX, SK, SO, NCO, STAGE>(ka, lds, true, (int)threadIdx.x);
+}
+// GLWE::trace(start, start + n) (ram.rs:457,540,572,616,621 and the packer levels in which every
+// leaf is alone) as ONE launch: n trace steps on the same ciphertext, one workgroup per ciphertext, ping-pong
+// between the workgroup's own slots of two buffers (see k_ext_product_chain).  Only the first step may read its
+// input rotated (write path).
+struct KsChainArgs {
+    KsArgs base;                     // a = source, rot_mul / rot_base of the first step, tw, big unused
+    GlweRef buf[2];                  // step i writes buf[i & 1] (buf[0] must not be the source)
+    const double* key[CHAIN_MAX];
+    int ginv[CHAIN_MAX];
+    int n;
+};
+template <int SX, int SK, int SO>
+__global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    KsArgs ka = ca.base;
+#pragma unroll 1
+    for (int i = 0; i < ca.n; i++) {
+        ka.out = ca.buf[i & 1];
+        ka.b = ka.a;
+        ka.key = ca.key[i];
+        ka.ginv = ca.ginv[i];
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));   // see k_ext_product_chain
+        ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
+        __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
+        ka.a = ka.out;
+        ka.rot_mul = 0;
+        ka.rot_base = 0;
     }
 }
 

@@ -106,13 +106,64 @@ void run_chain(fheram_ctx* c, int n, GlweRef src, GlweRef dst, GlweRef tmp, int 
         cur = out;
     }
 }
+// A dependent chain of n fused steps on the same ciphertexts runs as ONE launch when the batch is large enough
+// for the fused decomposition (one workgroup per ciphertext): the workgroup ping-pongs between its own slots
+// of two buffers.  bufs: step i writes b[i & 1]; b[0] must not be the source.
+bool use_chain(const fheram_ctx* c, int n, int gx, int gy, int sk) {
+    return c->chain && n >= 2 && n <= CHAIN_MAX && c->nco != 1 && !use_limb_split(c, gx, gy, sk) && pick_nco(c, gx, gy) == 2;
+}
+// picks (b0, b1) for a chain src -> dst with scratch tmp such that the last step lands in dst; false when the
+// first step would have to write what it reads (src == dst and n odd)
+bool chain_bufs(int n, GlweRef src, GlweRef dst, GlweRef tmp, GlweRef (&b)[2]) {
+    if (n % 2 == 1) { if (same(src, dst)) return false; b[0] = dst; b[1] = tmp; }
+    else { b[0] = tmp; b[1] = dst; }
+    return !same(b[0], src);
+}
+void launch_ep_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const double* prep, int d, int gx, int gy) {
+    ProfScope ps(c, "ext_product", (uint64_t)gx * gy, d);
+    ProfScope pf(c, "ext_product_fused", (uint64_t)gx * gy, d);
+    EpChainArgs ca;
+    ca.src = src; ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.tw = c->d_tw; ca.n = d;
+    for (int i = 0; i < d; i++) ca.ggsw[i] = prep + (size_t)i * fheram_ctx::GGSW;
+    hipLaunchKernelGGL((k_ext_product_chain<3, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+}
 // CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): d external products.
 void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, const double* prep, int d, int gx, int gy) {
+    if (gx <= 0 || gy <= 0) return;
+    if (use_chain(c, d, gx, gy, 4) && !use_fine_split(c, gx, gy, 2 * 4 * 2 * 3)) {
+        GlweRef b[2];
+        if (chain_bufs(d, src, dst, tmp, b)) { launch_ep_chain(c, src, b, prep, d, gx, gy); return; }
+        if (chain_bufs(d, src, tmp, dst, b)) {   // src == dst, d odd: finish in tmp, copy back
+            launch_ep_chain(c, src, b, prep, d, gx, gy);
+            launch_copy(c, tmp, dst, gx, gy);
+            return;
+        }
+    }
     run_chain(c, d, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) { launch_ep(c, in, out, prep + (size_t)i * fheram_ctx::GGSW, gx, gy); });
+}
+void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy, int rot_mul, int rot_base) {
+    ProfScope ps(c, "keyswitch", (uint64_t)gx * gy, n);
+    ProfScope pf(c, "keyswitch_fused", (uint64_t)gx * gy, n);
+    KsChainArgs ca;
+    ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
+    ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
+    for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
+    hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
 }
 // GLWE::trace(start, end): step i = rsh(1) then a += phi_{g_i}(KS(a)).
 // The first step may read its input rotated by X^-(x*rot_mul) (write path, ram.rs:621,629).
 void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start, int end, int gx, int gy, int rot_mul = 0, int rot_base = 0) {
+    if (gx <= 0 || gy <= 0) return;
+    const int n = end - start;
+    if (use_chain(c, n, gx, gy, 4) && !use_fine_split(c, gx, gy, 2 * 4 * 3)) {
+        GlweRef b[2];
+        if (chain_bufs(n, src, dst, tmp, b)) { launch_trace_chain(c, src, b, start, n, gx, gy, rot_mul, rot_base); return; }
+        if (chain_bufs(n, src, tmp, dst, b)) {
+            launch_trace_chain(c, src, b, start, n, gx, gy, rot_mul, rot_base);
+            launch_copy(c, tmp, dst, gx, gy);
+            return;
+        }
+    }
     run_chain(c, end - start, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) {
         KsArgs ka = ks_args(c, in, in, out, trace_key(c, start + i), c->gal[start + i], 0, i == 0 ? rot_mul : 0, i == 0 ? rot_base : 0);
         launch_ks<KS_TRACE, 3, 4, 3>(c, ka, gx, gy);
@@ -131,6 +182,13 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
     const int k = ilog2_ceil(count);
     int32_t* cur = src;
     auto other = [&](int32_t* x) { return x == A ? B : A; };
+    if (count > 0 && use_chain(c, n_alone, (int)count, gy, 4) && !use_fine_split(c, (int)count, gy, 2 * 4 * 3)) {
+        int32_t* b0 = other(cur);
+        int32_t* b1 = other(b0);
+        const GlweRef b[2] = {ref(b0, sy, sx), ref(b1, sy, sx)};
+        launch_trace_chain(c, ref(cur, sy, sx), b, 0, n_alone, (int)count, gy, 0, 0);
+        cur = ((n_alone - 1) & 1) ? b1 : b0;
+    } else
     for (int i = 0; i < n_alone; i++) {
         int32_t* nxt = other(cur);
         KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i]);
