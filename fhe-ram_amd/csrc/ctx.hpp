@@ -107,6 +107,16 @@ struct fheram_ctx {
     int32_t* d_ggsw_tmp2 = nullptr;
     int max_digits = 0;
     bool initialized = false, state = false, words_staged = false;
+    // Results of read_prepare_write that Ram::write recomputes on the unchanged state (FHERAM_MEMO=0 recomputes them):
+    //  memo_top  : d_trtop = trace(tree top) — the output of read_prepare_write (ram.rs:540) is the very value
+    //              write_first_step computes first (ram.rs:571-572: same ciphertext, same deterministic operations);
+    //  memo_alone: arena A holds every local row after the packer levels in which it is alone (ram.rs:514; n steps),
+    //              which ARE the first n steps of trace(ct_hi) in write_mid_step (ram.rs:616).
+    int memo = 1;
+    bool memo_top = false;
+    int memo_alone = 0;
+    int32_t* d_trtop = nullptr;    // [ws]
+    int32_t* d_trhi = nullptr;     // arena that holds trace(ct_hi) of the local rows during a write (A or C)
     int32_t* h_pin[2] = {nullptr, nullptr};   // pinned host staging (hand-over of int64 host buffers)
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
     // profiling

@@ -94,6 +94,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->limb_split = (ls && ls[0] == '0') ? 0 : 1;
         const char* fs = getenv("FHERAM_FINE_SPLIT");
         c->fine_split = (fs && fs[0] == '0') ? 0 : 1;
+        const char* mm = getenv("FHERAM_MEMO");
+        c->memo = (mm && mm[0] == '0') ? 0 : 1;
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* gr = getenv("FHERAM_GRAPH");
@@ -150,6 +152,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_res, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tmp, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_w, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_trtop, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_prep, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(double)));
     CCHK(hipMalloc(&c->d_ggsw_tmp, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     CCHK(hipMemset(c->d_tree, 0, (size_t)c->ws * G * sizeof(int32_t)));
@@ -173,7 +176,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_prep, c->d_ggsw_tmp};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -227,7 +230,7 @@ int fheram_ram_upload(fheram_ctx* c, const int64_t* rows) {
     HIPCHK(c, hipSetDevice(c->device));
     int rc = upload_i64(c, c->d_data, rows, (size_t)c->ws * c->rows * fheram_ctx::GLWE);
     if (rc != FHERAM_OK) return rc;
-    c->initialized = true; c->state = false;
+    c->initialized = true; c->state = false; c->memo_top = false; c->memo_alone = 0;
     return FHERAM_OK;
 }
 int fheram_ram_download(fheram_ctx* c, int64_t* rows) {

@@ -177,11 +177,18 @@ void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start
 // levels that stay inside one residue class (same n_alone / first_pair, count = local rows) and the
 // root finishes with n_alone = 0, first_pair = log N - log2(n_shards) over the gathered partials.
 // Returns the arena that holds the packed result at x = 0.
+// keep_alone (read_prepare_write): the rows after their alone levels are left in arena A, untouched by the
+// pairing levels, which then ping-pong between P0 and P1 (Ram::write resumes trace(ct_hi) from them).
 int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long sy, long sx, size_t count, int gy,
-                     int n_alone, int first_pair) {
+                     int n_alone, int first_pair, bool keep_alone = false, int32_t* P0 = nullptr, int32_t* P1 = nullptr) {
     const int k = ilog2_ceil(count);
     int32_t* cur = src;
     auto other = [&](int32_t* x) { return x == A ? B : A; };
+    if (keep_alone && n_alone > 0 && count > 0) {
+        // src -> ... -> A in n_alone out-of-place steps between A and B (src is neither)
+        trace_steps(c, ref(src, sy, sx), ref(A, sy, sx), ref(B, sy, sx), 0, n_alone, (int)count, gy);
+        cur = A;
+    } else
     if (count > 0 && use_chain(c, n_alone, (int)count, gy, 4) && !use_fine_split(c, (int)count, gy, 2 * 4 * 3)) {
         int32_t* b0 = other(cur);
         int32_t* b1 = other(b0);
@@ -199,7 +206,7 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
     for (int m = 0; m < k; m++) {
         const int i = first_pair + m;
         const long h = (long)1 << (k - 1 - m);
-        int32_t* nxt = other(cur);
+        int32_t* nxt = (keep_alone && P0) ? (cur == P0 ? P1 : P0) : other(cur);
         const long n_pair = std::max<long>(0, std::min<long>(h, (long)live - h));
         const long n_alone_here = std::min<long>(h, (long)live) - n_pair;
         if (n_pair > 0) {

@@ -70,7 +70,9 @@ int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweR
         leaves = c->d_scrA;
     }
     const int L0 = LOGN - ilog2_ceil(c->rows_glob);
-    int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws, L0, L0);   // ram.rs:435-448 / 510-521
+    const bool keep = prepare_write && c->memo && L0 > 0;   // leaves = d_data then: arena A keeps the rows after their alone levels
+    int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws, L0, L0, keep, c->d_scrC, c->d_scrD);   // ram.rs:435-448 / 510-521
+    c->memo_alone = keep ? L0 : 0;
     *packed_out = ref(packed, sy, 0);
     if (to_part) launch_copy(c, *packed_out, part, 1, ws);
     return FHERAM_OK;
@@ -103,6 +105,11 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
         }
     }                                                                                 // n2 == 1: res <- packed row (ram.rs:452 / 537)
     trace_steps(c, last, res, tmp, 0, LOGN, 1, ws);                                   // ram.rs:457 / 540
+    c->memo_top = false;
+    if (prepare_write && c->memo) {   // write_first_step's trace of the same ciphertext (ram.rs:571-572)
+        launch_copy(c, res, ref(c->d_trtop, G, 0), 1, ws);
+        c->memo_top = true;
+    }
     return FHERAM_OK;
 }
 int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
@@ -124,11 +131,14 @@ int write_top(fheram_ctx* c, const fheram_addr* addr) {
     GlweRef wref = ref(c->d_w, G, 0), tmp = ref(c->d_tmp, G, 0), tmp2 = ref(c->d_tmp2, G, 0), tree = ref(c->d_tree, G, 0);
     // write_first_step (ram.rs:544-577): t <- normalize(t - trace(t) + w)
     GlweRef top = (c->n2 != 1) ? tree : ref(c->d_data, sy, 0);
-    trace_steps(c, top, tmp, tmp2, 0, LOGN, 1, ws);
+    GlweRef tr = tmp;
+    if (c->memo_top) tr = ref(c->d_trtop, G, 0);      // = trace(top), computed by read_prepare_write on this very ciphertext
+    else trace_steps(c, top, tmp, tmp2, 0, LOGN, 1, ws);
     {
         ProfScope ps(c, "elementwise", ws);
-        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, top, tmp, wref, top);
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, top, tr, wref, top);
     }
+    c->memo_top = false;
     if (c->n2 == 2) {
         coordinate_prepare_inv(c, addr, 1, c->d_ggsw_tmp, c->d_prep);                 // ram.rs:260-271
         ep_chain(c, tree, tree, tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);     // ram.rs:610
@@ -151,7 +161,18 @@ void write_side_begin(fheram_ctx* c, const fheram_addr* addr) {
     hipEventRecord(c->ev_fork, c->stream);            // everything before this write (rows after rpw)
     hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
     c->cur = c->stream2;
-    if (c->n2 == 2) trace_steps(c, ref(c->d_data, sy, G), ref(c->d_scrA, sy, G), ref(c->d_scrC, sy, G), 0, LOGN, (int)c->rows, c->ws);
+    if (c->n2 == 2) {
+        c->d_trhi = c->d_scrA;
+        if (c->memo_alone > 0) {   // arena A = the rows after trace steps 0 .. memo_alone-1 (left there by read_prepare_write)
+            // ping-pong A <-> C; an odd number of remaining steps ends in C
+            if ((LOGN - c->memo_alone) % 2 == 1) c->d_trhi = c->d_scrC;
+            int32_t* tmp = c->d_trhi == c->d_scrA ? c->d_scrC : c->d_scrA;
+            trace_steps(c, ref(c->d_scrA, sy, G), ref(c->d_trhi, sy, G), ref(tmp, sy, G), c->memo_alone, LOGN, (int)c->rows, c->ws);
+        } else {
+            trace_steps(c, ref(c->d_data, sy, G), ref(c->d_scrA, sy, G), ref(c->d_scrC, sy, G), 0, LOGN, (int)c->rows, c->ws);
+        }
+        c->memo_alone = 0;
+    }
     coordinate_prepare_inv(c, addr, 0, c->d_ggsw_tmp2, c->d_prep2);
     hipEventRecord(c->ev_join, c->stream2);
     c->cur = c->stream;
@@ -170,12 +191,13 @@ int write_rows(fheram_ctx* c, const fheram_addr* addr) {
     const long sy = (long)c->rows * G;
     const int ws = c->ws, R = (int)c->rows;
     GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G), D = ref(c->d_scrD, sy, G);
+    GlweRef trhi = ref(c->d_trhi ? c->d_trhi : c->d_scrA, sy, G);
     if (c->n2 == 2)
         trace_steps(c, ref(c->d_part, G, 0), B, D, 0, LOGN, R, ws, c->n_shards, c->shard);     // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
     hipStreamWaitEvent(c->stream, c->ev_join, 0);                                              // side stream: trace(ct_hi), inverse coordinate 0
     if (c->n2 == 2) {
         ProfScope ps(c, "elementwise", (uint64_t)R * ws);
-        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws, EW_SLICES), dim3(256), 0, c->cur, data, A, B, data);   // ram.rs:617,625-626
+        hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws, EW_SLICES), dim3(256), 0, c->cur, data, trhi, B, data);   // ram.rs:617,625-626
     }
     ep_chain(c, data, data, A, c->d_prep2, (int)c->base2d[0].size(), R, ws);                   // ram.rs:644-646
     c->state = false;                                                                          // ram.rs:648

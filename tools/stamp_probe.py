@@ -14,7 +14,7 @@ L.fheram_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
 def probe(batch, label):
     a = synth((batch, ram.params.glwe_len()))
     for _ in range(3):
-        ram.glwe_trace(keys, 3, 4, a)      # one trace step = one k_keyswitch<KS_TRACE> launch
+        ram.glwe_trace(keys, 0, 6, a)      # six trace steps = one k_keyswitch_chain launch; the stamps are those of the last step
     st = (C.c_uint64 * 192)()
     L.fheram_debug_stamps(ram._h, st, 192)
     s = [int(x) for x in st]
