@@ -124,10 +124,15 @@ def host_cpu():
 
 
 def host_cores():
+    """threads of the all-core CPU baseline: the cores this process may use, capped at the GPU box's CPU share per GPU
+    (16; FHERAM_CPU_THREADS overrides)"""
+    if os.environ.get("FHERAM_CPU_THREADS"):
+        return int(os.environ["FHERAM_CPU_THREADS"])
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    return min(n, 16)
 
 
 def bench_ep(pkg, args):
@@ -369,10 +374,14 @@ def main():
                                 "reads, word upload on write; median; not part of `value`")
 
     if not args.no_kernel_timing:
-        classes = {k: ram.profile_get(k) for k in ("keyswitch", "keyswitch_fused", "ext_product", "ext_product_fused", "prepare", "elementwise")}
+        classes = {k: ram.profile_get(k) for k in ("keyswitch", "keyswitch_fused", "keyswitch_chain_launch", "ext_product",
+                                                   "ext_product_fused", "prepare", "elementwise")}
         kf = classes["keyswitch_fused"]
         # Dominant kernel = the fused key-switch at one workgroup per ciphertext (trace step / packer level over every
-        # row of every sub-RAM): k_keyswitch<KS_TRACE,3,4,3,2,0>.  Its launches are timed on their own.
+        # row of every sub-RAM).  Dependent trace steps on the same ciphertexts run as ONE launch (k_keyswitch_chain:
+        # 6 or 12 steps at 2^18); a "launch" below is one STEP of it (the unit SURVEY.md 8(d) counts bytes for:
+        # GLWE in + GLWE out per ciphertext, the step's key once), its duration = the launch's HIP-event time / steps.
+        # `chain_launch` carries the whole-launch figures that rocprofv3 --stats reports for k_keyswitch_chain.
         if kf["launches"]:
             avg_ms = kf["ms"] / kf["launches"]
             blocks = kf["blocks"] / kf["launches"]
@@ -380,12 +389,16 @@ def main():
             bytes_dev = blocks * 2 * (GLWE_I64 // 2) + ATK_I64       # what the device layout must move: int32 limbs, f64 key
             achieved = bytes_abi / avg_ms / 1e6
             fp64_per_block = 11 * 24576 * 8 + 24 * 4096 * 7         # 11 transforms x 24576 butterflies x 8 + 24 x 4096 MACs x 7
-            out["roofline"] = {"kernel": "k_keyswitch<KS_TRACE,3,4,3,NCO=2,STAGE=0> (fused trace step / packer level, one workgroup per ciphertext)",
+            out["roofline"] = {"kernel": "fused trace step (ks_run<KS_TRACE,3,4,3,NCO=2> inside k_keyswitch_chain<3,4,3> / k_keyswitch<1,3,4,3,2,0>), one workgroup per ciphertext",
                                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
                                "traffic_source": PMC_PROFILE + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                                  "FETCH_SIZE scaled by the factor calibrated on a known-bytes 4-B/lane int32 stream, tools/fetch_calib.hip)",
                                "avg_launch_ms": avg_ms, "avg_blocks_per_launch": blocks, "launches": kf["launches"],
+                               "chain_launch": ({"kernel": "k_keyswitch_chain<3,4,3>", "launches": classes["keyswitch_chain_launch"]["launches"],
+                                                 "avg_launch_ms": classes["keyswitch_chain_launch"]["ms"] / classes["keyswitch_chain_launch"]["launches"],
+                                                 "avg_steps_per_launch": classes["keyswitch_chain_launch"]["blocks"] / classes["keyswitch_chain_launch"]["launches"] / blocks}
+                                                if classes["keyswitch_chain_launch"]["launches"] else None),
                                "algorithmic_bytes_per_launch": bytes_abi,
                                "device_layout_bytes_per_launch": bytes_dev, "achieved_device_layout": bytes_dev / avg_ms / 1e6,
                                "frac_device_layout": bytes_dev / avg_ms / 1e6 / HBM_PEAK_GBS,

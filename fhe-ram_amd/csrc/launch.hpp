@@ -144,6 +144,7 @@ void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, const double
 void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy, int rot_mul, int rot_base) {
     ProfScope ps(c, "keyswitch", (uint64_t)gx * gy, n);
     ProfScope pf(c, "keyswitch_fused", (uint64_t)gx * gy, n);
+    ProfScope pl(c, "keyswitch_chain_launch", (uint64_t)gx * gy * n, 1);   // the launch itself, as rocprofv3 sees it
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;

@@ -1,0 +1,18 @@
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2q; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-boundary"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.json 2> $O/stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.json 2> $O/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.json 2> $O/write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cfetch -- $R/tools/fetch_calib > $O/cfetch.txt 2> $O/cfetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cwrite -- $R/tools/fetch_calib > $O/cwrite.txt 2> $O/cwrite.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/sq -- $B > $O/sq.json 2> $O/sq.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/lds -- $B > $O/lds.json 2> $O/lds.err
+cd $R
+python tools/trace_summary.py $O/stats 40 > $O/kernel_trace_by_grid.txt
+cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv
+python tools/pmc_hbm.py $O/cfetch $O/cwrite $O/fetch $O/write > $O/pmc_hbm_traffic.json
+python tools/pmc_sq_summary.py pmc_sq=$O/sq pmc_lds=$O/lds > $O/pmc_sq_summary.txt
+python bench.py > $O/bench.json 2> $O/bench.err
+rm -rf $O/stats $O/fetch $O/write $O/cfetch $O/cwrite $O/sq $O/lds
+ls -la $O

@@ -58,18 +58,30 @@ for key in sorted(set(bf) | set(bw), key=str):
         e["WRITE_SIZE_KiB_per_launch"] = mean(v)
         e["write_bytes_per_launch"] = mean(v) * 1024.0 * w4
     kern[f"{name} grid_threads={grid}"] = e
-dom = None
-for k, e in kern.items():
-    if "k_keyswitch<1, 3, 4, 3, 2, 0>" in k and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e:
-        if dom is None or e["launches"] > kern[dom]["launches"]:
-            dom = k
 out = {"calibration": calib,
        "calibration_note": "factor = known bytes / counter bytes for a streaming pass over 96 MiB; the RAM rows are read 4 B per lane "
                            "(k_read4's pattern), the prepared keys 16 B per lane (L2 resident, a small share of the fabric reads)",
        "kernels": kern}
-if dom:
-    e = kern[dom]
-    out["dominant_kernel"] = {"kernel": dom, "launches": e["launches"], "read_bytes_per_launch": e["read_bytes_per_launch"],
-                              "write_bytes_per_launch": e["write_bytes_per_launch"],
-                              "hbm_bytes_per_launch": e["read_bytes_per_launch"] + e["write_bytes_per_launch"]}
+
+
+def dominant(kern):
+    """The dominant kernel shape = one fused trace step over 256 ciphertexts.  It runs inside k_keyswitch_chain (6 or 12 steps
+    per launch at 2^18) or as k_keyswitch<1,3,4,3,2,0>; every step writes exactly blocks * 98 304 B, which gives the steps of a launch."""
+    for pat in ("k_keyswitch_chain<3, 4, 3>", "k_keyswitch<1, 3, 4, 3, 2, 0>"):
+        cand = [(k, e) for k, e in kern.items() if pat in k and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e]
+        if cand:
+            k, e = max(cand, key=lambda ke: ke[1]["launches"])
+            blocks = int(k.split("grid_threads=")[1]) // 512
+            steps = e["write_bytes_per_launch"] / (blocks * 98304.0)
+            return {"kernel": k, "launches": e["launches"], "ciphertexts_per_step": blocks, "steps_per_launch": steps,
+                    "read_bytes_per_step": e["read_bytes_per_launch"] / steps, "write_bytes_per_step": e["write_bytes_per_launch"] / steps,
+                    "hbm_bytes_per_launch": (e["read_bytes_per_launch"] + e["write_bytes_per_launch"]) / steps,
+                    "note": "hbm_bytes_per_launch is per STEP (one trace step over all ciphertexts = what bench.py's roofline calls a launch); "
+                            "compulsory for the int32 device layout: 2 x 98 304 B per ciphertext + the 786 432 B key"}
+    return None
+
+
+dk = dominant(kern)
+if dk:
+    out["dominant_kernel"] = dk
 print(json.dumps(out, indent=1))
