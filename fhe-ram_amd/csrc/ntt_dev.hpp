@@ -97,6 +97,15 @@ constexpr bool wave_local() { return (LOGN - LOGE * (X + 1)) <= 6; }
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// Hand-off inside ONE wave (wave-local exchanges): the lanes' LDS writes must be ordered before the other lanes'
+// reads.  The hardware executes a wave's DS operations in order; this makes the ordering a guarantee of the
+// memory model too (no instruction is emitted for wavefront scope: the compiler merely may not move or merge
+// LDS accesses across it).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // B polynomials are transformed together: one LDS exchange moves all of them, and the B
 // independent butterfly streams give the FP64 pipe more ILP.
@@ -114,7 +123,7 @@ __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, in
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X>(tid, k))] = x[b][k];
-    if constexpr (!wave_local<X>()) lds_barrier();
+    if constexpr (!wave_local<X>()) lds_barrier(); else wave_lds_fence();
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
@@ -133,7 +142,7 @@ __device__ __forceinline__ void exchange_inv(double (&x)[B][E], double* data, in
     for (int b = 0; b < B; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) data[b * LDS_DATA + lay<X>(pat<X + 1>(tid, k))] = x[b][k];
-    if constexpr (!wave_local<X>()) lds_barrier();
+    if constexpr (!wave_local<X>()) lds_barrier(); else wave_lds_fence();
 #pragma unroll
     for (int b = 0; b < B; b++)
 #pragma unroll
