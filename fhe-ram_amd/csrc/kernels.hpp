@@ -339,6 +339,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product_chain(EpChainArgs ca
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));   // per-step copy the optimiser cannot see through: keeps it from hoisting every
                                         // thread-index-derived address out of the step loop (56 spilled registers)
+        __builtin_assume(tid >= 0 && tid < T);   // ... but it may still use the range (index patterns fold to immediates)
         ep_run<SA, SG, 2, 0>(in, out, ca.ggsw[i], ca.tw, nullptr, lds, i == 0, tid);
         __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
         in = out;
@@ -810,6 +811,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) 
         ka.ginv = ca.ginv[i];
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
+        __builtin_assume(tid >= 0 && tid < T);
         ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
         __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
         ka.a = ka.out;

@@ -26,7 +26,7 @@ constexpr int N = 1 << LOGN;
 #define FK_LOGE 3
 #endif
 #ifndef FK_XCHG_REG
-#define FK_XCHG_REG 0   // 1: wave-local exchanges as register-lane transposes (DPP / v_permlane*_swap) instead of LDS
+#define FK_XCHG_REG 0   // 1: both wave-local exchanges as register-lane transposes (DPP / v_permlane*_swap) instead of LDS; 2: only exchange 1 (lane bits 3..5: the permlane swaps)
 #endif
 constexpr int LOGE = FK_LOGE;    // log2(coefficients per thread): 3 (512 threads) or 4 (256 threads)
 static_assert(LOGN % LOGE == 0, "radix must divide log N");
@@ -117,7 +117,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int X, int B> __device__ __forceinline__ void exchange_reg(double (&x)[B][E], int tid);
 template <int X, int B>
 __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, int tid) {
-    if constexpr (FK_XCHG_REG && wave_local<X>()) { exchange_reg<X, B>(x, tid); return; }
+    if constexpr ((FK_XCHG_REG == 1 && wave_local<X>()) || (FK_XCHG_REG == 2 && X == 1)) { exchange_reg<X, B>(x, tid); return; }
     if constexpr (!wave_local<X>()) lds_barrier();   // cross-wave readers of the previous transform are done
 #pragma unroll
     for (int b = 0; b < B; b++)
@@ -134,7 +134,7 @@ __device__ __forceinline__ void exchange_fwd(double (&x)[B][E], double* data, in
 }
 template <int X, int B>
 __device__ __forceinline__ void exchange_inv(double (&x)[B][E], double* data, int tid) {
-    if constexpr (FK_XCHG_REG && wave_local<X>()) { exchange_reg<X, B>(x, tid); return; }
+    if constexpr ((FK_XCHG_REG == 1 && wave_local<X>()) || (FK_XCHG_REG == 2 && X == 1)) { exchange_reg<X, B>(x, tid); return; }
     // no barrier before the write when everything since the fence at the start of ntt_inv was wave
     // local; a second cross-wave exchange (radix 4 only) must fence the readers of the one before it
     if constexpr (!wave_local<X>() && !wave_local<X + 1>()) lds_barrier();
