@@ -101,7 +101,8 @@ struct fheram_ctx {
     int nco = 0;                   // output columns per workgroup: 1 = split by column (2 workgroups per
                                    // ciphertext), 2 = one workgroup, 0 = choose per launch from the batch size
     int cus = 256;
-    double* d_prep = nullptr;      // [max digits per coordinate] prepared GGSW
+    double* d_prep = nullptr;      // [n_digits] prepared GGSW: coordinate ci at its first digit (write: inverse digits at 0)
+    bool prep1_ready = false;      // coordinate 1 was prepared together with coordinate 0 (unsharded reads)
     double* d_prep2 = nullptr;     // second set (inverse coordinate 0, prepared on the side stream)
     int32_t* d_ggsw_tmp = nullptr; // [max digits per coordinate] std GGSW (inversion result)
     int32_t* d_ggsw_tmp2 = nullptr;

@@ -153,7 +153,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_tmp, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_w, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_trtop, (size_t)c->ws * G * sizeof(int32_t)));
-    CCHK(hipMalloc(&c->d_prep, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(double)));
+    CCHK(hipMalloc(&c->d_prep, (size_t)std::max(c->n_digits, c->max_digits) * fheram_ctx::GGSW * sizeof(double)));
     CCHK(hipMalloc(&c->d_ggsw_tmp, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     CCHK(hipMemset(c->d_tree, 0, (size_t)c->ws * G * sizeof(int32_t)));
 #undef CCHK

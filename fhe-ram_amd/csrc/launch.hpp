@@ -225,9 +225,16 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
 }
 // CoordinatePrepared::prepare (coordinate_prepared.rs:104-116) for coordinate `ci` of addr.
 int coord_first_digit(const fheram_ctx* c, int ci) { int s = 0; for (int i = 0; i < ci; i++) s += (int)c->base2d[i].size(); return s; }
+// The prepared digits of coordinate ci live at prep_of(c, ci) inside d_prep ([n_digits] prepared GGSW).
+double* prep_of(const fheram_ctx* c, int ci) { return c->d_prep + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW; }
 void coordinate_prepare(fheram_ctx* c, const fheram_addr* addr, int ci) {
     const int d = (int)c->base2d[ci].size();
-    launch_prepare(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, c->d_prep, d * (int)(fheram_ctx::GGSW / N));
+    launch_prepare(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, prep_of(c, ci), d * (int)(fheram_ctx::GGSW / N));
+}
+// every coordinate of the address in ONE launch (the reference prepares coordinate i at the top of loop iteration i,
+// ram.rs:416-419; nothing in between depends on the order)
+void coordinate_prepare_all(fheram_ctx* c, const fheram_addr* addr) {
+    launch_prepare(c, addr->d_ggsw, c->d_prep, c->n_digits * (int)(fheram_ctx::GGSW / N));
 }
 // CoordinatePrepared::prepare_inv (coordinate_prepared.rs:121-142): GGSW(X^i) -> GGSW(X^-i).
 void ggsw_inverse(fheram_ctx* c, const int32_t* in, int32_t* tmp, int d) {

@@ -47,26 +47,28 @@ int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweR
     const int R = (int)c->rows;
     GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G);
     GlweRef part = ref(c->d_part, G, 0);
-    coordinate_prepare(c, addr, 0);                                                   // ram.rs:416-419 / 496-499
+    const bool all = (c->n_shards == 1 && c->n2 == 2);   // unsharded: both coordinates now, one launch
+    if (all) coordinate_prepare_all(c, addr); else coordinate_prepare(c, addr, 0);    // ram.rs:416-419 / 496-499
+    c->prep1_ready = all;
     const int d0 = (int)c->base2d[0].size();
     if (c->n2 == 1) {
         GlweRef row0 = ref(c->d_data, sy, 0);
         if (prepare_write) {
-            ep_chain(c, row0, row0, ref(c->d_scrA, sy, 0), c->d_prep, d0, 1, ws);     // ram.rs:502-504 (rows == 1)
+            ep_chain(c, row0, row0, ref(c->d_scrA, sy, 0), prep_of(c, 0), d0, 1, ws);     // ram.rs:502-504 (rows == 1)
             *packed_out = row0;
             if (to_part) launch_copy(c, row0, part, 1, ws);
         } else {
-            ep_chain(c, row0, part, ref(c->d_tmp, G, 0), c->d_prep, d0, 1, ws);       // ram.rs:451
+            ep_chain(c, row0, part, ref(c->d_tmp, G, 0), prep_of(c, 0), d0, 1, ws);       // ram.rs:451
             *packed_out = part;
         }
         return FHERAM_OK;
     }
     int32_t* leaves;
     if (prepare_write) {
-        ep_chain(c, data, data, A, c->d_prep, d0, R, ws);                             // ram.rs:502-504
+        ep_chain(c, data, data, A, prep_of(c, 0), d0, R, ws);                             // ram.rs:502-504
         leaves = c->d_data;
     } else {
-        ep_chain(c, data, A, B, c->d_prep, d0, R, ws);                                // ram.rs:429-434
+        ep_chain(c, data, A, B, prep_of(c, 0), d0, R, ws);                                // ram.rs:429-434
         leaves = c->d_scrA;
     }
     const int L0 = LOGN - ilog2_ceil(c->rows_glob);
@@ -94,13 +96,14 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
             int32_t* packed = pack_levels(c, gathered, a0, a1, G, (long)ws * G, (size_t)c->n_shards, ws, 0, LOGN - kG);
             pk = ref(packed, G, 0);
         }
-        coordinate_prepare(c, addr, 1);
+        if (!c->prep1_ready) coordinate_prepare(c, addr, 1);
+        c->prep1_ready = false;
         const int d1 = (int)c->base2d[1].size();
         if (prepare_write) {
-            ep_chain(c, pk, tree, tmp, c->d_prep, d1, 1, ws);                         // ram.rs:525-527 + 502-504 (i = 1): tree[0] <- rotated packed row
+            ep_chain(c, pk, tree, tmp, prep_of(c, 1), d1, 1, ws);                         // ram.rs:525-527 + 502-504 (i = 1): tree[0] <- rotated packed row
             last = tree;                                                              // ram.rs:535 (res <- tree[0])
         } else {
-            ep_chain(c, pk, res, tmp, c->d_prep, d1, 1, ws);                          // ram.rs:454
+            ep_chain(c, pk, res, tmp, prep_of(c, 1), d1, 1, ws);                          // ram.rs:454
             last = res;
         }
     }                                                                                 // n2 == 1: res <- packed row (ram.rs:452 / 537)

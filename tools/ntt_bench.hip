@@ -198,6 +198,84 @@ __global__ __launch_bounds__(T, T / 256) void k_bench_split(const double* __rest
     sink[blockIdx.x * T + tid] = s;
 }
 
+// The NEXT limb's pointwise MAC (3 operand polynomials, 168 FP64 instructions per thread) as filler of the LDS
+// round trips of the current inverse transform: one operand polynomial's worth after the DS operations of each of
+// the three exchanges have been issued, before the pass that consumes the exchanged data.
+//   FILL 0: transform, then the MAC (what the fused kernels do);  FILL 1: interleaved.
+template <int X>
+__device__ __forceinline__ void xchg_issue(double (&x)[E], double (&y)[E], double* buf, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) buf[lay<X>(pat<X + 1>(tid, k))] = x[k];
+    if constexpr (!wave_local<X>()) lds_barrier(); else wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < E; k++) y[k] = buf[lay<X>(pat<X>(tid, k))];
+    __builtin_amdgcn_sched_barrier(0);   // the DS operations are issued before whatever follows
+}
+// FILL 2: the same filler, but spread between the individual DS operations (one DS write / read, then 3-4 FP64
+// instructions): a wave issues in order, so a DS operation that finds the LDS queue full holds up everything behind it
+template <int X, typename F>
+__device__ __forceinline__ void xchg_spread(double (&x)[E], double (&y)[E], double* buf, int tid, F&& half) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < E; k++) buf[lay<X>(pat<X + 1>(tid, k))] = x[k];
+    half(0);
+#pragma unroll
+    for (int i = 0; i < E; i++) { __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 4, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!wave_local<X>()) lds_barrier(); else wave_lds_fence();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < E; k++) y[k] = buf[lay<X>(pat<X>(tid, k))];
+    half(1);
+#pragma unroll
+    for (int i = 0; i < E; i++) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 4, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int FILL>
+__global__ __launch_bounds__(T, T / 256) void k_bench_fill(const double* __restrict__ tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = threadIdx.x;
+    load_twiddles(tw, tw_g, tid);
+    double x[E], y[E], op[3][E], xh[3][E], acc[E];
+    for (int k = 0; k < E; k++) { x[k] = (double)(tid * 8 + k); acc[k] = 0; for (int r = 0; r < 3; r++) { op[r][k] = 1000.0 + r + k + tid; xh[r][k] = 77.0 * r + k + tid; } }
+    auto chunk = [&](int q) {
+#pragma unroll
+        for (int k = 0; k < E; k++) acc[k] = macmod(acc[k], xh[q][k], op[q][k]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int r = 0; r < reps; r++) {
+        for (int k = 0; k < E; k++) { x[k] = reduce(x[k]); acc[k] = 0.0; }
+        TwPass t;
+        double* buf = data + (r & 1) * LDS_DATA;
+        inv_twiddles<3>(t, tw, tid);
+        inv_pass<3>(x, t); x[0] = reduce(x[0]); x[1] = reduce(x[1]);
+        inv_twiddles<2>(t, tw, tid);
+        auto halfq = [&](int q, int h) {
+#pragma unroll
+            for (int k = 4 * h; k < 4 * h + 4; k++) acc[k] = macmod(acc[k], xh[q][k], op[q][k]);
+        };
+        if (FILL == 2) xchg_spread<2>(x, y, buf, tid, [&](int h) { halfq(0, h); });
+        else { xchg_issue<2>(x, y, buf, tid); if (FILL) chunk(0); }
+        inv_pass<2>(y, t); y[0] = reduce(y[0]); y[1] = reduce(y[1]);
+        inv_twiddles<1>(t, tw, tid);
+        if (FILL == 2) xchg_spread<1>(y, x, buf, tid, [&](int h) { halfq(1, h); });
+        else { xchg_issue<1>(y, x, buf, tid); if (FILL) chunk(1); }
+        inv_pass<1>(x, t); x[0] = reduce(x[0]); x[1] = reduce(x[1]);
+        inv_twiddles<0>(t, tw, tid);
+        if (FILL == 2) xchg_spread<0>(x, y, buf, tid, [&](int h) { halfq(2, h); });
+        else { xchg_issue<0>(x, y, buf, tid); if (FILL) chunk(2); }
+        inv_pass<0>(y, t);
+        for (int k = 0; k < E; k++) x[k] = reduce(y[k]);
+        if (!FILL) { chunk(0); chunk(1); chunk(2); }
+        for (int k = 0; k < E; k++) xh[0][k] += acc[k] * 1e-30;   // keep the MAC alive
+    }
+    double s_ = 0;
+    for (int k = 0; k < E; k++) s_ += x[k] + xh[0][k];
+    sink[blockIdx.x * T + tid] = s_;
+}
+
 // Prototype of the other decomposition: one WAVE per polynomial as a 64 x 64 four-step transform.  Lane b holds
 // the 64 coefficients {64 a + b}: a 64-point transform over a in registers (twiddles wave-uniform: scalar
 // loads), a twist by a per-element factor, one transpose through LDS, a second 64-point transform.  No
@@ -464,6 +542,9 @@ int main() {
     run_wave<2>(tw, sink, 256);
     run_pipe2(k_bench_split<0>, "transform + MAC, s_barrier then MAC (x2)", tw, sink, 256);
     run_pipe2(k_bench_split<1>, "transform + MAC in a split software barrier (x2)", tw, sink, 256);
+    run_pipe2(k_bench_fill<0>, "transform, then the next limb's MAC (x2)", tw, sink, 256);
+    run_pipe2(k_bench_fill<1>, "next limb's MAC inside the exchanges' round trips (x2)", tw, sink, 256);
+    run_pipe2(k_bench_fill<2>, "next limb's MAC spread between the DS operations (x2)", tw, sink, 256);
     run_pipe2(k_bench_gtw<1>, "double buffered, no twiddles in LDS (x2)", tw, sink, 256);
     run_pipe2(k_bench_sgpr<1>, "double buffered + scalar twiddles in passes 0,1 (x2)", tw, sink, 256);
     run_pipe2(k_bench_asm<1, 1>, "full, un-merged ds_read_b64 (x2 = per transform)", tw, sink, 256);
