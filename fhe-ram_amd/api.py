@@ -97,6 +97,12 @@ _SYMBOLS = [
     ("fheram_address_encrypt_sk", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, I64P, I64P, C.POINTER(C.c_void_p)]),
     ("fheram_address_download", C.c_int, [C.c_void_p, C.c_void_p, I64P]),
     ("fheram_keys_encrypt_sk", C.c_int, [C.c_void_p, C.c_void_p, I64P, I64P, I64P]),
+    ("fheram_fheuint_ggsw_len", C.c_size_t, [C.c_void_p]),
+    ("fheram_fheuint_create", C.c_int, [C.c_void_p, I64P, C.c_int, C.POINTER(C.c_void_p)]),
+    ("fheram_fheuint_encrypt_sk", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, I64P, I64P, C.POINTER(C.c_void_p)]),
+    ("fheram_fheuint_download", C.c_int, [C.c_void_p, C.c_void_p, I64P]),
+    ("fheram_fheuint_destroy", None, [C.c_void_p]),
+    ("fheram_address_set_from_fheuint", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     ("fheram_timer_begin", C.c_int, [C.c_void_p]),
     ("fheram_timer_end", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("fheram_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
@@ -305,6 +311,19 @@ class Address:
         return self
 
     @classmethod
+    def set_from_fheuint(cls, ram: "Ram", fheuint: "FheUintPrepared", sign: bool = True):
+        """Address::set_from_fheuint (conversion.rs:68-82): every digit derived from the encrypted integer on the
+        device.  sign=True: digits of X^{+digit} (what the reference's test decrypts to); sign=False: X^{-digit}, the
+        convention of Address::encrypt_sk (address.rs:102-108), i.e. an address Ram.read accepts."""
+        self = cls.__new__(cls)
+        self.base2d = ram.params.base2d()
+        out = C.c_void_p()
+        ram._chk(library().fheram_address_set_from_fheuint(ram._h, fheuint._h, int(bool(sign)), C.byref(out)))
+        self._digits = None
+        self._handles = {id(ram): _AddrHandle(out.value, ram)}
+        return self
+
+    @classmethod
     def alloc_from_params(cls, params: Parameters):  # address.rs:58
         glen = params.ggsw_len()
         return cls(params, [np.zeros(glen, dtype=np.int64) for _ in range(params.base2d().as_1d().size())])
@@ -326,6 +345,44 @@ class Address:
             h = _AddrHandle(out.value, ram)
             self._handles[id(ram)] = h
         return h.h
+
+
+class FheUintPrepared:
+    """poulpy-schemes' FheUintPrepared<u32> as the RAM path needs it (conversion.rs:68-82): one GGSW per bit of an
+    encrypted integer, LSB first, on a Ram's device.  Layout: k = k_evk_ggsw_inv, 5 limbs, dnum 4 (include/fheram.h)."""
+
+    def __init__(self, ram: "Ram", handle, n_bits):
+        self.ram, self._h, self.n_bits = ram, handle, n_bits
+
+    @classmethod
+    def from_host(cls, ram: "Ram", bits):
+        bits = _i64(bits)
+        out = C.c_void_p()
+        ram._chk(library().fheram_fheuint_create(ram._h, _p(bits), bits.shape[0], C.byref(out)))
+        return cls(ram, out.value, bits.shape[0])
+
+    @classmethod
+    def encrypt_sk(cls, ram: "Ram", value: int, sk: "GLWESecret", source_xa, source_xe, n_bits: int = 32):
+        """FheUintPrepared::encrypt_sk (conversion.rs:160-168) with host-side sources, as the other encrypt_sk mirrors."""
+        p = ram.params
+        n, b2k, k = p.n(), p.basek(), p.k_evk_ggsw_inv()
+        size = -(-k // b2k)
+        n_glwe = n_bits * p.dnum_ggsw() * 2
+        mask = source_xa.uniform_limbs(n_glwe * size * n)
+        noise = source_xe.gaussian(n_glwe * n, noise_scale(k, b2k))
+        out = C.c_void_p()
+        ram._chk(library().fheram_fheuint_encrypt_sk(ram._h, sk._h, int(value), n_bits, _p(mask), _p(noise), C.byref(out)))
+        return cls(ram, out.value, n_bits)
+
+    def download(self) -> np.ndarray:
+        out = np.zeros((self.n_bits, library().fheram_fheuint_ggsw_len(self.ram._h)), dtype=np.int64)
+        self.ram._chk(library().fheram_fheuint_download(self.ram._h, self._h, _p(out)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.fheram_fheuint_destroy(self._h)
+            self._h = None
 
 
 class _AddrHandle:

@@ -72,6 +72,7 @@ struct fheram_ctx {
     static constexpr size_t GGSW = (size_t)DNUM_CT * 2 * GLWE4;            // elements of a GGSW
     static constexpr size_t ATK = (size_t)DNUM_CT * S_EVK * 2 * N;         // trace key
     static constexpr size_t EVK5 = (size_t)DNUM_GGSW * S_INV * 2 * N;      // inverse / tensor key
+    static constexpr size_t GGSW5 = (size_t)DNUM_GGSW * 2 * S_INV * 2 * N; // one bit of an FheUint (N4)
     // device
     double* d_tw = nullptr;
     double ninv = 0.0;
@@ -134,6 +135,13 @@ struct fheram_addr {
     int n_digits;
     int device;
     hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // captured launch sequences: read, read_prepare_write, write
+};
+
+struct fheram_fheuint {
+    fheram_ctx* ctx;
+    int device, n_bits;
+    int32_t* d_std;    // [n_bits] std-form GGSW (5 limbs, dnum 4), int32
+    double* d_prep;    // the same, prepared
 };
 
 struct fheram_secret {

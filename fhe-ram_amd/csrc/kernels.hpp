@@ -1128,6 +1128,41 @@ __global__ __launch_bounds__(256) void k_rotate(GlweRef a, GlweRef out, int rho)
     }
 }
 
+// CMux steps of Address::set_from_fheuint (conversion.rs:41-65; see fheram_address_set_from_fheuint):
+// out = normalize(a * X^rho - a)
+template <int S>
+__global__ __launch_bounds__(256) void k_cmux_pre(GlweRef a, GlweRef out, int rho) {
+    const int32_t* ap = at(a);
+    int32_t* op = at(out);
+    for (int idx = blockIdx.z * blockDim.x + threadIdx.x; idx < 2 * N; idx += blockDim.x * gridDim.z) {
+        const int col = idx >> LOGN, i = idx & (N - 1);
+        int src; bool sgn;
+        rot_src(i, rho, src, sgn);
+        double in_l[S], out_l[S];
+#pragma unroll
+        for (int j = 0; j < S; j++) in_l[j] = (double)(cneg(ap[glwe_off(j, col) + src], sgn) - ap[glwe_off(j, col) + i]);
+        normalize_coeff<S, S>(in_l, out_l);
+#pragma unroll
+        for (int j = 0; j < S; j++) op[glwe_off(j, col) + i] = (int)out_l[j];
+    }
+}
+// out = normalize(a + b)   (out may be a)
+template <int S>
+__global__ __launch_bounds__(256) void k_add_norm(GlweRef a, GlweRef b, GlweRef out) {
+    const int32_t* ap = at(a);
+    const int32_t* bp = at(b);
+    int32_t* op = at(out);
+    for (int idx = blockIdx.z * blockDim.x + threadIdx.x; idx < 2 * N; idx += blockDim.x * gridDim.z) {
+        const int col = idx >> LOGN, i = idx & (N - 1);
+        double in_l[S], out_l[S];
+#pragma unroll
+        for (int j = 0; j < S; j++) in_l[j] = (double)(ap[glwe_off(j, col) + i] + bp[glwe_off(j, col) + i]);
+        normalize_coeff<S, S>(in_l, out_l);
+#pragma unroll
+        for (int j = 0; j < S; j++) op[glwe_off(j, col) + i] = (int)out_l[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Setup side: GLWE::encrypt_sk / decrypt with HOST-sampled randomness.
 // The host lays down a pre-ciphertext (body = plaintext limbs + the noise polynomial on its

@@ -356,4 +356,141 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     return FHERAM_OK;
 }
 
+// ---- Address::set_from_fheuint (conversion.rs:18-82) ---------------------------------------
+size_t fheram_fheuint_ggsw_len(const fheram_ctx*) { return fheram_ctx::GGSW5; }
+namespace {
+int fheuint_alloc(fheram_ctx* c, int n_bits, fheram_fheuint** out) {
+    fheram_fheuint* f = new fheram_fheuint{c, c->device, n_bits, nullptr, nullptr};
+    hipError_t e = hipMalloc(&f->d_std, (size_t)n_bits * fheram_ctx::GGSW5 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&f->d_prep, (size_t)n_bits * fheram_ctx::GGSW5 * sizeof(double));
+    if (e != hipSuccess) { fheram_fheuint_destroy(f); return fail(c, FHERAM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    *out = f;
+    return FHERAM_OK;
+}
+int fheuint_prepare(fheram_ctx* c, fheram_fheuint* f) {
+    c->cur = c->stream;
+    launch_prepare(c, f->d_std, f->d_prep, f->n_bits * (int)(fheram_ctx::GGSW5 / N));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return FHERAM_OK;
+}
+}  // namespace
+int fheram_fheuint_create(fheram_ctx* c, const int64_t* bits, int n_bits, fheram_fheuint** out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!bits || n_bits <= 0 || n_bits > 64) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    fheram_fheuint* f = nullptr;
+    int rc = fheuint_alloc(c, n_bits, &f);
+    if (rc == FHERAM_OK) rc = upload_i64(c, f->d_std, bits, (size_t)n_bits * fheram_ctx::GGSW5);
+    if (rc == FHERAM_OK) rc = fheuint_prepare(c, f);
+    if (rc != FHERAM_OK) { fheram_fheuint_destroy(f); return rc; }
+    *out = f;
+    return FHERAM_OK;
+}
+int fheram_fheuint_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, uint32_t value, int n_bits, const int64_t* mask,
+                              const int64_t* noise, fheram_fheuint** out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!mask || !noise || n_bits <= 0 || n_bits > 32) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    const int S = fheram_ctx::S_INV, k = (int)c->p.k_evk_ggsw_inv, D = fheram_ctx::DNUM_GGSW;
+    int rc = check_setup_args(c, sk, S, k);
+    if (rc != FHERAM_OK) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t glen = (size_t)S * 2 * N;
+    const int n = n_bits * D * 2;
+    std::vector<int32_t> pre((size_t)n * glen, 0), pt1((size_t)n * S * N, 0);
+    int gi = 0;
+    for (int i = 0; i < n_bits; i++) {
+        const int32_t bit = (int32_t)((value >> i) & 1);
+        for (int r = 0; r < D; r++)
+            for (int ci = 0; ci < 2; ci++, gi++) {
+                int32_t* pg = pre.data() + (size_t)gi * glen;
+                if (ci == 0) pg[(size_t)(r * 2) * N] = bit;            // row r: b * 2^-((r+1)*base2k) in the body
+                else pt1[((size_t)gi * S + r) * N] = bit;              //        b * s * ..., added to the mask column
+                if (!stage_random(pg, S, k, mask + (size_t)gi * S * N, noise + (size_t)gi * N))
+                    return fail(c, FHERAM_ERR_RANGE, "mask limb outside [-2^16, 2^16) or |noise| >= 2^30");
+            }
+    }
+    fheram_fheuint* f = nullptr;
+    rc = fheuint_alloc(c, n_bits, &f);
+    if (rc == FHERAM_OK) rc = encrypt_staged(c, sk->d_hat, f->d_std, pre, &pt1, n, S);
+    if (rc == FHERAM_OK) rc = fheuint_prepare(c, f);
+    wipe_host(pre.data(), pre.size() * sizeof(int32_t)); wipe_host(pt1.data(), pt1.size() * sizeof(int32_t));
+    if (rc != FHERAM_OK) { fheram_fheuint_destroy(f); return rc; }
+    *out = f;
+    return FHERAM_OK;
+}
+int fheram_fheuint_download(fheram_ctx* c, const fheram_fheuint* f, int64_t* out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    if (!f || f->ctx != c) return fail(c, FHERAM_ERR_INVALID_ARG, "integer belongs to another context");
+    HIPCHK(c, hipSetDevice(c->device));
+    return download_i64(c, out, f->d_std, (size_t)f->n_bits * fheram_ctx::GGSW5);
+}
+void fheram_fheuint_destroy(fheram_fheuint* f) {
+    if (!f) return;
+    hipSetDevice(f->device);
+    if (f->d_std) hipFree(f->d_std);
+    if (f->d_prep) hipFree(f->d_prep);
+    delete f;
+}
+// conversion.rs:41-65.  For every row of every digit: acc = trivial encryption of the gadget element, then one CMux per
+// bit of the digit: acc <- normalize(acc + normalize(X^(+-2^(i+lsh)) acc - acc) (x) GGSW(b_i)).  The external products run
+// on the fine-split kernels (one workgroup per input and output limb: 80 per row), all 6 rows of a digit per launch.
+int fheram_address_set_from_fheuint(fheram_ctx* c, const fheram_fheuint* f, int sign, fheram_addr** out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!f || f->ctx != c) return fail(c, FHERAM_ERR_INVALID_ARG, "integer belongs to another context");
+    unsigned bits = 0;
+    for (auto& b1 : c->base2d) for (int b : b1) bits += (unsigned)b;
+    if ((int)bits > f->n_bits) return fail(c, FHERAM_ERR_INVALID_ARG, "the address plan is wider than the encrypted integer");
+    HIPCHK(c, hipSetDevice(c->device));
+    constexpr int S = fheram_ctx::S_ADDR, SG = fheram_ctx::S_INV, D = fheram_ctx::DNUM_CT;
+    const long g4 = (long)fheram_ctx::GLWE4;
+    const int rows = D * 2;                                    // GLWEs per digit
+    fheram_addr* a = new fheram_addr{c, nullptr, c->n_digits, c->device};
+    DevBuf tbuf, ebuf;
+    double* big = nullptr;
+    hipError_t e = hipMalloc(&a->d_ggsw, (size_t)c->n_digits * fheram_ctx::GGSW * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&tbuf.p, (size_t)rows * g4 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&ebuf.p, (size_t)rows * g4 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&big, (size_t)rows * 2 * SG * 2 * S * N * sizeof(double));
+    if (e != hipSuccess) { if (big) hipFree(big); fheram_address_destroy(a); return fail(c, FHERAM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    {   // test_vector = X^0 (conversion.rs:42-43) on gadget row r: body limb r for col_in 0, mask limb r for col_in 1
+        std::vector<int32_t> h((size_t)c->n_digits * fheram_ctx::GGSW, 0);
+        for (int d = 0; d < c->n_digits; d++)
+            for (int r = 0; r < D; r++)
+                for (int ci = 0; ci < 2; ci++) h[((size_t)(d * D + r) * 2 + ci) * g4 + (size_t)(r * 2 + ci) * N] = 1;
+        e = hipMemcpy(a->d_ggsw, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
+    c->cur = c->stream;
+    int digit = 0;
+    unsigned bit_rsh = 0;
+    for (auto& base1d : c->base2d) {                                                      // :45
+        unsigned bit_lsh = 0;                                                             // :46
+        for (int bit_mask : base1d) {                                                     // :49
+            GlweRef acc = ref(a->d_ggsw + (size_t)digit * fheram_ctx::GGSW, 0, g4);
+            GlweRef t = ref(tbuf.p, 0, g4), ev = ref(ebuf.p, 0, g4);
+            for (int i = 0; i < bit_mask; i++) {
+                const int step = 1 << (i + bit_lsh);
+                const double* gb = f->d_prep + (size_t)(bit_rsh + i) * fheram_ctx::GGSW5;
+                ProfScope ps(c, "set_from_fheuint", rows);
+                hipLaunchKernelGGL((k_cmux_pre<S>), dim3(rows, 1, EW_SLICES), dim3(256), 0, c->cur, acc, t, sign ? step : -step);
+                hipLaunchKernelGGL((k_ext_product_fine<S, SG>), dim3(rows, 1, 2 * SG * 2 * S), dim3(T), LDS_BYTES, c->cur, t, gb, c->d_tw, big);
+                hipLaunchKernelGGL((k_ext_product_fine_norm<S, SG>), dim3(rows, 1, 2 * (N / 256)), dim3(256), 0, c->cur, ev, big);
+                hipLaunchKernelGGL((k_add_norm<S>), dim3(rows, 1, EW_SLICES), dim3(256), 0, c->cur, acc, ev, acc);
+            }
+            bit_lsh += (unsigned)bit_mask;                                                // :61
+            bit_rsh += (unsigned)bit_mask;                                                // :62
+            digit++;
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    hipFree(big);
+    if (e != hipSuccess) { fheram_address_destroy(a); return fail(c, FHERAM_ERR_DEVICE, std::string("set_from_fheuint: ") + hipGetErrorString(e)); }
+    *out = a;
+    return FHERAM_OK;
+}
+
 }  // extern "C"

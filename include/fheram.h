@@ -213,6 +213,27 @@ int fheram_address_download(fheram_ctx* ctx, const fheram_addr* addr, int64_t* o
 int fheram_keys_encrypt_sk(fheram_ctx* ctx, const fheram_secret* sk, const int64_t* mask, const int64_t* noise,
                            int64_t* std_out);
 
+/* ---- Address::set_from_fheuint (conversion.rs:18-82).  The reference derives every address
+ * digit from an encrypted integer with poulpy-schemes' scalar_to_ggsw_blind_rotation (un-vendored); what is built
+ * here is its CONTRACT (conversion.rs:41-65 and the test at :100-220), by CMux chains on noiseless GGSW rows with
+ * the external-product kernels — a self-consistent restatement, bit-exact against the in-repo oracle only.
+ * FheUintPrepared<u32> = one GGSW per bit, LSB first, in the layout of the GGSW-inversion keys
+ * (k = k_evk_ggsw_inv, 5 limbs, dnum 4): [n_bits][row 4][col_in 2][limb 5][col_out 2][N] int64. */
+typedef struct fheram_fheuint fheram_fheuint;
+size_t fheram_fheuint_ggsw_len(const fheram_ctx* ctx);
+/* FheUintPrepared::alloc + prepare from host ciphertexts. */
+int fheram_fheuint_create(fheram_ctx* ctx, const int64_t* bits, int n_bits, fheram_fheuint** out);
+/* FheUintPrepared::encrypt_sk (conversion.rs:160-168) on the device with host-drawn randomness (as the other
+ * encrypt_sk entry points): mask [n_bits][4][2][5][N], noise [n_bits][4][2][N]. */
+int fheram_fheuint_encrypt_sk(fheram_ctx* ctx, const fheram_secret* sk, uint32_t value, int n_bits, const int64_t* mask,
+                              const int64_t* noise, fheram_fheuint** out);
+int fheram_fheuint_download(fheram_ctx* ctx, const fheram_fheuint* fu, int64_t* out);
+void fheram_fheuint_destroy(fheram_fheuint* fu);
+/* Address::set_from_fheuint (conversion.rs:68-82): digit d = GGSW of X^{+-(((k >> bit_rsh) mod 2^bit_mask) << bit_lsh)}
+ * over the context's digit plan; sign != 0: + (what the reference's test decrypts to), 0: - (the convention of
+ * Address::encrypt_sk, address.rs:102-108, i.e. an address Ram::read accepts). */
+int fheram_address_set_from_fheuint(fheram_ctx* ctx, const fheram_fheuint* fu, int sign, fheram_addr** out);
+
 /* ---- Measurement hooks (bench.py).  HIP events recorded on the context's own stream. */
 int fheram_timer_begin(fheram_ctx* ctx);
 int fheram_timer_end(fheram_ctx* ctx, float* elapsed_ms);

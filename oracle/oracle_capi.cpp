@@ -168,6 +168,29 @@ int fo_ggsw_encrypt(void* c, const int64_t* scalar, const int64_t* sk, uint64_t 
     FO_CATCH
 }
 
+// ---- N4: Address::set_from_fheuint (conversion.rs:18-82), self-consistent restatement ------------
+size_t fo_fheuint_ggsw_len(void* c) { Ctx* x = (Ctx*)c; return (size_t)x->p.dnum_ggsw() * 2 * x->p.glwe_len(x->p.size_evk_inv()); }
+// FheUintPrepared::encrypt_sk stand-in: one GGSW per bit (LSB first), out [n_bits][fo_fheuint_ggsw_len]
+int fo_fheuint_encrypt(void* c, uint32_t value, int n_bits, const int64_t* sk, uint64_t seed_a, uint64_t seed_e, int64_t* out) {
+    FO_TRY
+    Ctx* x = (Ctx*)c; Source xa(seed_a), xe(seed_e); PolyHat h; to_hat_prepared(x->ntt, sk, h);
+    std::vector<int64_t> scalar(x->n(), 0);
+    for (int i = 0; i < n_bits; i++) {
+        scalar[0] = (value >> i) & 1;
+        ggsw_encrypt_sk(*x, out + (size_t)i * fo_fheuint_ggsw_len(c), x->p.dnum_ggsw(), x->p.size_evk_inv(), x->p.k_evk_ggsw_inv, scalar.data(), h, xa, xe);
+    }
+    FO_CATCH
+}
+int fo_address_from_fheuint(void* c, const int64_t* bits_std, int n_bits, int sign, int64_t* out_digits) {
+    FO_TRY
+    Ctx* x = (Ctx*)c;
+    FheUint fu; fheuint_prepare(*x, fu, bits_std, n_bits);
+    Address a; address_set_from_fheuint(*x, a, fu, sign != 0);
+    size_t k = 0;
+    for (auto& co : a.coordinates) for (auto& g : co.value) { std::memcpy(out_digits + k * x->p.ggsw_len(), g.data(), sizeof(int64_t) * g.size()); k++; }
+    FO_CATCH
+}
+
 // ---- prepared keys / address handles --------------------------------------------------
 void* fo_keys_prepare(void* c, const int64_t* gal_els, int n_gal, const int64_t* atk_glwe, const int64_t* atk_inv, const int64_t* tsk) {
     try {

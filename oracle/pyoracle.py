@@ -465,6 +465,27 @@ class Oracle:
         _chk(lib().fo_ggsw_automorphism_inv(self.h, keys.h, _p(np.ascontiguousarray(ggsw).ravel()), _p(out)))
         return out
 
+    # -- N4: Address::set_from_fheuint (conversion.rs:18-82)
+    def fheuint_ggsw_len(self):
+        lib().fo_fheuint_ggsw_len.restype = C.c_size_t
+        lib().fo_fheuint_ggsw_len.argtypes = [C.c_void_p]
+        return int(lib().fo_fheuint_ggsw_len(self.h))
+
+    def fheuint_encrypt(self, value, n_bits, sk, seed_a, seed_e):
+        """one GGSW per bit of `value` (LSB first), [n_bits][fheuint_ggsw_len]"""
+        out = np.zeros((n_bits, self.fheuint_ggsw_len()), dtype=np.int64)
+        lib().fo_fheuint_encrypt.argtypes = [C.c_void_p, C.c_uint32, C.c_int, I64P, C.c_uint64, C.c_uint64, I64P]
+        _chk(lib().fo_fheuint_encrypt(self.h, int(value), n_bits, _p(sk), seed_a, seed_e, _p(out)))
+        return out
+
+    def address_from_fheuint(self, bits_std, sign=True):
+        """std-form GGSW digits [n_digits][ggsw_len] of X^{+-digit} derived from the encrypted bits"""
+        bits_std = np.ascontiguousarray(bits_std, dtype=np.int64)
+        out = np.zeros((self.n_digits, self.p.ggsw_len), dtype=np.int64)
+        lib().fo_address_from_fheuint.argtypes = [C.c_void_p, I64P, C.c_int, C.c_int, I64P]
+        _chk(lib().fo_address_from_fheuint(self.h, _p(bits_std), bits_std.shape[0], int(sign), _p(out)))
+        return out
+
     def ram_new(self):
         return ORam(self)
 
