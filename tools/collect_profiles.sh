@@ -1,7 +1,7 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2q; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-boundary"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-boundary > $O/stats.json 2> $O/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.json 2> $O/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.json 2> $O/write.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cfetch -- $R/tools/fetch_calib > $O/cfetch.txt 2> $O/cfetch.err
@@ -16,3 +16,8 @@ python tools/pmc_sq_summary.py pmc_sq=$O/sq pmc_lds=$O/lds > $O/pmc_sq_summary.t
 python bench.py > $O/bench.json 2> $O/bench.err
 rm -rf $O/stats $O/fetch $O/write $O/cfetch $O/cwrite $O/sq $O/lds
 ls -la $O
+python bench.py --log-max-addr 12 --no-cpu-baseline > $O/bench_2_12.json 2> $O/bench_2_12.err
+python bench.py --log-max-addr 21 --steps 5 --no-cpu-baseline > $O/bench_2_21.json 2> $O/bench_2_21.err
+python bench.py --workload ep > $O/bench_ep.json 2> $O/bench_ep.err
+./tools/ntt_bench > $O/ntt_bench.txt 2>&1
+./tools/xcd_handoff > $O/xcd_handoff.txt 2>&1
