@@ -163,6 +163,33 @@ public:
         chk(fheram_address_encrypt_sk(ctx_, sk.h_, value, mask.data(), noise.data(), &a.h_));
         a.owner_ = this;
     }
+    // poulpy-schemes' FheUintPrepared<u32> as the path needs it (conversion.rs:68-82): one GGSW per bit, on this device
+    class FheUintPrepared {
+    public:
+        // FheUintPrepared::encrypt_sk (conversion.rs:160-168) with the caller's samplers
+        FheUintPrepared(Ram& ram, uint32_t value, const Secret& sk, Source& source_xa, Source& source_xe, int n_bits = 32) {
+            const size_t n = ram.params.n(), b = ram.params.basek(), k = ram.params.p.k_evk_ggsw_inv;
+            const size_t size = (k + b - 1) / b, dnum = (ram.params.p.k_ggsw_addr + b - 1) / b, glwes = (size_t)n_bits * dnum * 2;
+            std::vector<int64_t> mask(glwes * size * n), noise(glwes * n);
+            source_xa.uniform_limbs(mask.data(), mask.size());
+            source_xe.gaussian(noise.data(), noise.size(), noise_scale((uint32_t)k, (uint32_t)b));
+            ram.chk(fheram_fheuint_encrypt_sk(ram.ctx_, sk.h_, value, n_bits, mask.data(), noise.data(), &h_));
+        }
+        // from host ciphertexts: [n_bits][fheram_fheuint_ggsw_len]
+        FheUintPrepared(Ram& ram, const std::vector<int64_t>& bits, int n_bits) { ram.chk(fheram_fheuint_create(ram.ctx_, bits.data(), n_bits, &h_)); }
+        ~FheUintPrepared() { if (h_) fheram_fheuint_destroy(h_); }
+        FheUintPrepared(const FheUintPrepared&) = delete;
+    private:
+        friend class Ram;
+        fheram_fheuint* h_ = nullptr;
+    };
+    // Address::set_from_fheuint, conversion.rs:68-82 (sign = false: the convention of Address::encrypt_sk, i.e. an
+    // address Ram::read accepts; true: what the reference's test decrypts to)
+    void set_from_fheuint(Address& a, const FheUintPrepared& fheuint, bool sign = false) {
+        if (a.h_) { fheram_address_destroy(a.h_); a.h_ = nullptr; }
+        chk(fheram_address_set_from_fheuint(ctx_, fheuint.h_, sign ? 1 : 0, &a.h_));
+        a.owner_ = this;
+    }
     // EvaluationKeys::encrypt_sk + EvaluationKeysPrepared::prepare, keys.rs:135-180,57-71: generated and
     // prepared on this context; `keys` is marked as the set in use (its std forms stay empty).
     void encrypt_keys(EvaluationKeysPrepared& keys, const Secret& sk, Source& source_xa, Source& source_xe) {

@@ -36,6 +36,14 @@ int main() {
             if (((got - want) & ((1 << 17) - 1)) != 0) { std::printf("word %zu: got %lld want %lld\n", i, (long long)got, (long long)want); return 5; }
         }
         std::printf("device-side setup + read + decrypt: ok\n");
+        // Address::set_from_fheuint (conversion.rs:68-82): the same word through an address derived from an encrypted integer
+        fheram::Ram::FheUintPrepared fu(ram, idx, dsk, xa, xe, 12);
+        fheram::Address derived;
+        ram.set_from_fheuint(derived, fu);
+        std::vector<int64_t> pt2 = ram.decrypt(ram.read(derived, keys), dsk);
+        for (size_t i = 0; i < 4; i++)
+            if (((pt2[i * 3 * p.n()] - pt[i * 3 * p.n()]) & ((1 << 17) - 1)) != 0) { std::printf("derived address: word %zu differs\n", i); return 6; }
+        std::printf("address derived from an encrypted integer reads the same word: ok\n");
     } catch (const fheram::Error& e) {
         if (e.code != FHERAM_ERR_DEVICE) return 4;
         std::printf("no GPU: %s\n", e.what());
