@@ -328,7 +328,7 @@ int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* ad
     else if (!c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
     if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_write_root / fheram_write_shard");
     rc = run_op(c, addr, 2, [&] {
-        write_side_begin(c, addr);
+        if (!c->side_begun) write_side_begin(c, addr);   // (fheram_write_begin may have started it)
         int r2 = write_top(c, addr);
         return r2 == FHERAM_OK ? write_rows(c, addr) : r2;
     });

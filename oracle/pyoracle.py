@@ -30,7 +30,7 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("FO_LIB") or os.path.join(_HERE, "liboracle.so")   # FO_LIB: e.g. the sanitizer build liboracle_asan.so
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

@@ -37,3 +37,19 @@ def test_bench_sharded_one_rank_rccl_device_buffers():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = last_json(r.stdout)
     assert out["mode"] == "sharded" and out["value"] > 0
+
+
+def test_bench_sharded_two_ranks_gloo_on_one_gpu():
+    """N = 2 ranks of bench.py's default mode (ONE RAM sharded over the ranks), rehearsed on the one GPU with gloo and
+    host exchange buffers: weak scaling (2^13 entries per rank) and strong scaling (--total-log-max-addr 14)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra, scaling in (([], "weak"), (["--total-log-max-addr", "14"], "strong")):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29557", os.path.join(ROOT, "bench.py"),
+                            "--gpus", "2", "--dist-backend", "gloo", "--all-ranks-device0", "--log-max-addr", "13",
+                            "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"] + extra,
+                           capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out = last_json(r.stdout)
+        assert out["mode"] == "sharded" and out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
+        assert "MAX_ADDR=2^14" in out["config"]["workload"]
