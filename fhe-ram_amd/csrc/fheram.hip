@@ -114,19 +114,21 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product_fine<4, 5>));
     LDSATTR((&k_ext_product_chain<3, 4>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
-#define LDSATTR_KS(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
+#define LDSATTR_KS4(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
+#define LDSATTR_KS(M, SX, SK, SO) LDSATTR_KS4(M, SX, SK, SO); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);
     LDSATTR_KS(KS_TRACE, 3, 4, 3);
-    LDSATTR_KS(KS_PAIR, 3, 4, 3);
+    LDSATTR_KS4(KS_PAIR, 3, 4, 3);
     LDSATTR_KS(KS_ADD, 3, 4, 3);
     LDSATTR_KS(KS_SUBNEG, 3, 4, 3);
-    LDSATTR_KS(KS_AUTO, 4, 5, 4);
-    LDSATTR_KS(KS_TENSOR, 4, 5, 4);
+    LDSATTR_KS4(KS_AUTO, 4, 5, 4);
+    LDSATTR_KS4(KS_TENSOR, 4, 5, 4);
     LDSATTR((&k_encrypt_sk<1, 1>));
     LDSATTR((&k_encrypt_sk<3, 0>)); LDSATTR((&k_encrypt_sk<3, 1>));
     LDSATTR((&k_encrypt_sk<4, 0>)); LDSATTR((&k_encrypt_sk<4, 1>));
     LDSATTR((&k_encrypt_sk<5, 0>)); LDSATTR((&k_encrypt_sk<5, 1>));
 #undef LDSATTR_KS
+#undef LDSATTR_KS4
 #undef LDSATTR
 
     std::vector<double> tw = make_twiddles();

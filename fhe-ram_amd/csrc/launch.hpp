@@ -69,8 +69,13 @@ void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
         hipLaunchKernelGGL((k_keyswitch_norm<MODE, SX, SK, SO>), dim3(gx, gy, 2 * (N / 256)), dim3(256), 0, c->cur, kb);
         return;
     }
-    if (pick_nco(c, gx, gy) == 1) hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);
-    else {
+    // The two-column fused form exists for the 3-limb automorphism family only: the 4-limb GGSW-inversion steps and
+    // the packer combine always run split by column (their fused forms spill registers; at 2^21, where pair levels
+    // have up to 1024 pairs, the split combine is 3 % faster per read than the spilling fused one was).
+    constexpr bool FUSABLE = (SX == 3) && (MODE != KS_PAIR);
+    if (!FUSABLE || pick_nco(c, gx, gy) == 1) {
+        hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);
+    } else if constexpr (FUSABLE) {
         ProfScope pf(c, "keyswitch_fused", (uint64_t)gx * gy);     // the dominant launch shape (one workgroup per ciphertext)
         hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ka);
     }
