@@ -118,6 +118,8 @@ struct fheram_ctx {
     bool memo_top = false;
     int memo_alone = 0;
     int32_t* d_trtop = nullptr;    // [ws]
+    int32_t* d_last_res = nullptr; // where the last read / read_prepare_write left its result (d_res or d_trtop)
+    bool tree_rotate_pending = false;
     int32_t* d_trhi = nullptr;     // arena that holds trace(ct_hi) of the local rows during a write (A or C)
     int32_t* h_pin[2] = {nullptr, nullptr};   // pinned host staging (hand-over of int64 host buffers)
     hipEvent_t ev_pin[2] = {nullptr, nullptr};

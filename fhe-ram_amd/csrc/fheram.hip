@@ -278,7 +278,7 @@ void fheram_address_destroy(fheram_addr* a) {
 int fheram_result_download(fheram_ctx* c, int64_t* out) {
     if (!c || !out) return FHERAM_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    return download_i64(c, out, c->d_res, (size_t)c->ws * fheram_ctx::GLWE);
+    return download_i64(c, out, c->d_last_res ? c->d_last_res : c->d_res, (size_t)c->ws * fheram_ctx::GLWE);
 }
 int fheram_sync(fheram_ctx* c) {
     if (!c) return FHERAM_ERR_INVALID_ARG;

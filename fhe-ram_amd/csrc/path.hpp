@@ -24,6 +24,15 @@ int run_op(fheram_ctx* c, const fheram_addr* addr, int which, F&& enqueue) {
         if (e2 != hipSuccess) { a->graph[which] = nullptr; return fail(c, FHERAM_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
     }
     HIPCHK(c, hipGraphLaunch(a->graph[which], c->stream));
+    // the host-side bookkeeping the enqueue functions do (a replay does not run them)
+    const int L0 = LOGN - ilog2_ceil(c->rows_glob);
+    if (which == 0) { c->memo_top = false; c->d_last_res = c->d_res; }
+    else if (which == 1) {
+        c->memo_top = c->memo != 0;
+        c->d_last_res = c->memo_top ? c->d_trtop : c->d_res;
+        c->memo_alone = (c->memo && c->n2 == 2 && L0 > 0) ? L0 : 0;
+    } else { c->memo_top = false; c->memo_alone = 0; c->side_begun = false; c->tree_rotate_pending = false; }
+    c->prep1_ready = false;
     return FHERAM_OK;
 }
 
@@ -107,12 +116,11 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
             last = res;
         }
     }                                                                                 // n2 == 1: res <- packed row (ram.rs:452 / 537)
-    trace_steps(c, last, res, tmp, 0, LOGN, 1, ws);                                   // ram.rs:457 / 540
-    c->memo_top = false;
-    if (prepare_write && c->memo) {   // write_first_step's trace of the same ciphertext (ram.rs:571-572)
-        launch_copy(c, res, ref(c->d_trtop, G, 0), 1, ws);
-        c->memo_top = true;
-    }
+    // read_prepare_write: the result is also what write_first_step computes first (trace of the same ciphertext,
+    // ram.rs:571-572): it lands in d_trtop, which no read overwrites, and stays there for the write
+    c->memo_top = prepare_write && c->memo;
+    c->d_last_res = c->memo_top ? c->d_trtop : c->d_res;
+    trace_steps(c, last, ref(c->d_last_res, G, 0), tmp, 0, LOGN, 1, ws);              // ram.rs:457 / 540
     return FHERAM_OK;
 }
 int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
@@ -144,13 +152,10 @@ int write_top(fheram_ctx* c, const fheram_addr* addr) {
     c->memo_top = false;
     if (c->n2 == 2) {
         coordinate_prepare_inv(c, addr, 1, c->d_ggsw_tmp, c->d_prep);                 // ram.rs:260-271
-        ep_chain(c, tree, tree, tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);     // ram.rs:610
-        launch_copy(c, tree, ref(c->d_part, G, 0), 1, ws);
-        {   // ct_lo ends up rotated `rows` times by X^-1 (ram.rs:629)
-            ProfScope ps(c, "elementwise", ws);
-            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, tree, tmp, -(int)c->rows_glob);
-        }
-        launch_copy(c, tmp, tree, 1, ws);
+        ep_chain(c, tree, ref(c->d_part, G, 0), tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);   // ram.rs:610: the un-rotated ct_lo, in d_part
+        // tree[0] <- ct_lo * X^-rows (ram.rs:629, `rows` rotations by X^-1): nothing in this write reads it again, so
+        // the rotation is enqueued behind the rows' work (write_rows) instead of in front of it
+        c->tree_rotate_pending = true;
     }
     return FHERAM_OK;
 }
@@ -197,6 +202,11 @@ int write_rows(fheram_ctx* c, const fheram_addr* addr) {
     GlweRef trhi = ref(c->d_trhi ? c->d_trhi : c->d_scrA, sy, G);
     if (c->n2 == 2)
         trace_steps(c, ref(c->d_part, G, 0), B, D, 0, LOGN, R, ws, c->n_shards, c->shard);     // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
+    if (c->tree_rotate_pending) {   // root / unsharded: the tree's copy of ct_lo, rotated (see write_top)
+        ProfScope ps(c, "elementwise", ws);
+        hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, ref(c->d_part, G, 0), ref(c->d_tree, G, 0), -(int)c->rows_glob);
+        c->tree_rotate_pending = false;
+    }
     hipStreamWaitEvent(c->stream, c->ev_join, 0);                                              // side stream: trace(ct_hi), inverse coordinate 0
     if (c->n2 == 2) {
         ProfScope ps(c, "elementwise", (uint64_t)R * ws);
