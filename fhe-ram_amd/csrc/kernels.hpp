@@ -520,7 +520,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
     // requested at the very start, pre-stepped once and kept as packed words (three 18-bit fields, 2 VGPRs per
     // coefficient): pa0 / pa1 = what the post-step adds to column 0 / 1 (x itself; KS_PAIR: the pair sum),
     // pbody = x column 0 for the body staging.  Without this every column began with a global round trip of
-    // its own (4.3 + 2.1 us of a 50 us kernel, profiles/r02_stamps_keyswitch.txt).
+    // its own (4.3 + 2.1 us of a 50 us kernel, profiles/r02_stamps_keyswitch_unchained.txt).
     // (not for the fused two-column KS_PAIR: three packed operands per coefficient do not fit its registers)
     constexpr bool FAST = PHI && SX == 3 && STAGE == 0 && !(MODE == KS_PAIR && NCO == 2);
     constexpr bool HAS_XA = (MODE == KS_TRACE || MODE == KS_ADD || MODE == KS_SUBNEG || MODE == KS_PAIR);
