@@ -12,3 +12,11 @@ def test_soak_every_launch_decomposition_reproducible_and_exact(po):
     import soak_gpu
     rounds, checks = soak_gpu.main(seconds=25, seed=20261003)
     assert rounds >= 20 and checks >= 40
+
+
+def test_soak_whole_ram_flows_over_random_shapes(po):
+    """tests/soak_flow_gpu.py for a bounded time: random RAM sizes (ragged rows, 1 and 2 coordinates), word sizes, digit
+    plans and addresses through read / read_prepare_write / write / read-back, every output and the whole state
+    bit-identical to the oracle's."""
+    import soak_flow_gpu
+    assert soak_flow_gpu.main(seconds=25, seed=20261004) >= 2
