@@ -1,5 +1,10 @@
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2q; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+# Collects the round's profile set on an MI355X box (run through gpurun); summaries land in gpurun_out/r2q, from where
+# the ones to be judged are copied into profiles/.  Counters are collected in separate passes (FETCH_SIZE, WRITE_SIZE, SQ).
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r2q; mkdir -p $O
+for t in fetch_calib xcd_handoff; do [ -x $R/tools/$t ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/$t $R/tools/$t.hip; done
+[ -x $R/tools/ntt_bench ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I$R/fhe-ram_amd/csrc -o $R/tools/ntt_bench $R/tools/ntt_bench.hip
+cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-boundary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-boundary > $O/stats.json 2> $O/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.json 2> $O/fetch.err
