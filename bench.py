@@ -430,8 +430,8 @@ def main():
         cores = host_cores()
         r, q, w = cpu_baseline(max_addr, ws, 99, cores)
         out["cpu_baseline_allcores"] = {"value": 2.0 / (r + q + w), "unit": "RAM ops/s", "cores": cores, "kind": "port",
-                                        "sample": f"oracle, OpenMP over the {ws} sub-RAMs and the rows of the per-row loops (packer sequential per "
-                                                  f"sub-RAM, as in the reference), whole 2^{args.log_max_addr} RAM, one step",
+                                        "sample": f"oracle, OpenMP over the {ws} sub-RAMs and over the rows (per-row loops; packing level by level with "
+                                                  f"the leaves of a level in parallel), whole 2^{args.log_max_addr} RAM, one step",
                                         "read_ms": r * 1e3, "read_prepare_write_ms": q * 1e3, "write_ms": w * 1e3, "host_cpu": host_cpu()}
     print(json.dumps(out))
     if dist is not None:

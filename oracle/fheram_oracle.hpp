@@ -130,8 +130,9 @@ struct Ctx {
     std::atomic<uint64_t> n_ep{0}, n_ks{0}, n_prepare{0};
     // threads > 1: the all-core CPU baseline.  Sub-RAMs are independent (ram.rs:187-190 maps
     // over them one after the other) and so are the rows inside the per-row loops (ram.rs:429-434, 502-504,
-    // 612-630, 644-646); OpenMP runs those loops in parallel.  The packer stays sequential per sub-RAM, as
-    // in the reference.  Results are identical to threads = 1 (every ciphertext sees the same operations).
+    // 612-630, 644-646); OpenMP runs those loops in parallel, and the packing runs level by level with the leaves of a
+    // level in parallel (pack_level_sync).  Results are identical to threads = 1 (every ciphertext sees the same
+    // operations; tests/test_oracle.py, and the committed digests of the full sizes are produced this way).
     int threads = 1;
     explicit Ctx(const Params& p_) : p(p_), ntt(p_.log_n) {}
     int n() const { return p.n(); }
@@ -423,6 +424,39 @@ static inline void ggsw_automorphism(Ctx& c, int64_t* res, const int64_t* a, int
     }
 }
 
+// All-core variant of the packing (Ctx::threads > 1): the same combines as the sequential GLWEPacker fed in
+// bit-reversed order, scheduled level by level so that the leaves of a level run in parallel.  With count leaves
+// (k = ceil(log2 count), L0 = log N - k): every leaf first goes alone through packer levels 0..L0-1
+// (combine(acc, None, i)); then pairing round m joins leaf q with leaf q + 2^(k-1-m) at packer level L0 + m, a leaf
+// without partner goes through that level alone.  (This is the schedule of the HIP path, csrc/launch.hpp pack_levels;
+// tests/test_oracle.py checks it against the sequential packer, ragged counts included.)  leaves[q] is consumed.
+static inline void pack_level_sync(Ctx& c, std::vector<std::vector<int64_t>>& leaves, int size, int64_t* res,
+                                   const std::map<int64_t, KeyPrepared>& keys, int nth) {
+    const int log_n = c.p.log_n;
+    const size_t count = leaves.size();
+    int k = 0; while (((size_t)1 << k) < count) k++;
+    const int L0 = log_n - k;
+    Packer dummy; dummy.n = c.n(); dummy.size = size;
+    auto combine = [&](std::vector<int64_t>& a, const int64_t* b, int level) {
+        Accumulator acc; acc.data.swap(a); acc.value = true; acc.control = true;
+        packer_combine(c, dummy, acc, b, level, keys);
+        a.swap(acc.data);
+    };
+#pragma omp parallel for num_threads(nth) schedule(dynamic)
+    for (size_t q = 0; q < count; q++)
+        for (int i = 0; i < L0; i++) combine(leaves[q], nullptr, i);
+    size_t live = count;
+    for (int m = 0; m < k; m++) {
+        const int level = L0 + m;
+        const size_t h = (size_t)1 << (k - 1 - m);
+        const size_t top = std::min(h, live);
+#pragma omp parallel for num_threads(nth) schedule(dynamic)
+        for (size_t q = 0; q < top; q++) combine(leaves[q], (q + h < live) ? leaves[q + h].data() : nullptr, level);
+        live = top;
+    }
+    std::memcpy(res, leaves[0].data(), sizeof(int64_t) * leaves[0].size());
+}
+
 // =======================================================================================
 // coordinate.rs / address.rs / coordinate_prepared.rs
 // =======================================================================================
@@ -583,6 +617,11 @@ struct Ram {                                                     // ram.rs:25-29
                     prod.assign(total, std::vector<int64_t>(glen()));
 #pragma omp parallel for num_threads(nth) schedule(dynamic)
                     for (size_t r = 0; r < total; r++) coordinate_product(*c, cp, view(prod[r]), view(res_prev[r]));
+                    if (total <= n) {   // one chunk (always, for max_addr <= N^2): pack level by level, in parallel
+                        pack_level_sync(*c, prod, c->p.size_ct(), tmp_ct.data(), keys.atk_glwe, nth);
+                        results.push_back(tmp_ct);
+                        continue;
+                    }
                 }
                 for (size_t base = 0; base < total; base += n) {                      // chunks(n) :424
                     const size_t chunk_len = std::min(n, total - base);
@@ -623,6 +662,12 @@ struct Ram {                                                     // ram.rs:25-29
             coordinate_prepare(*c, cp, coordinate);                                   // :496-499
 #pragma omp parallel for num_threads(c->inner_threads()) schedule(dynamic)
             for (size_t r = 0; r < res_prev.size(); r++) coordinate_product_inplace(*c, cp, view(res_prev[r]));   // :502-504
+            if (i < address.n2() - 1 && c->inner_threads() > 1 && res_prev.size() <= n) {
+                std::vector<std::vector<int64_t>> leaves = res_prev;   // the rows stay as they are (ram.rs:514 packs copies)
+                pack_level_sync(*c, leaves, c->p.size_ct(), tmp_ct.data(), keys.atk_glwe, c->inner_threads());
+                results.push_back(tmp_ct);
+                for (size_t k = 0; k < std::min(s.tree[i].size(), results.size()); k++) s.tree[i][k] = results[k];   // :525-527
+            } else
             if (i < address.n2() - 1) {
                 const size_t total = res_prev.size();
                 for (size_t base = 0; base < total; base += n) {                      // :510

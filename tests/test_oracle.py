@@ -236,16 +236,22 @@ def test_all_core_variant_equals_one_thread(po):
     full sizes) runs sub-RAMs and rows concurrently; every ciphertext sees the same operations, so the
     results must be identical to the sequential restatement."""
     import numpy as np
+    for max_addr in (5 * 4096, 2 * 4096, 7 * 4096 - 100):
+        _all_core_case(po, max_addr)
+
+
+def _all_core_case(po, max_addr):
+    import numpy as np
     outs = []
     for th in (1, 4):
-        o = po.Oracle(po.OParams(max_addr=5 * 4096, word_size=2)).set_threads(th)
+        o = po.Oracle(po.OParams(max_addr=max_addr, word_size=2)).set_threads(th)
         sk = o.secret_gen(1)
         keys = o.keys_prepare(o.evk_gen(sk, 2, 3))
         rng = np.random.default_rng(4)
-        data = rng.integers(0, 256, size=5 * 4096 * 2, dtype=np.uint8)
+        data = rng.integers(0, 256, size=max_addr * 2, dtype=np.uint8)
         ram = o.ram_new()
         ram.load(o.ram_encrypt(data, sk, 5, 6))
-        addr = o.address_new(o.address_encrypt(3 * 4096 + 17, sk, 7, 8))
+        addr = o.address_new(o.address_encrypt(max_addr - 4096 + 17, sk, 7, 8))
         w = np.stack([o.glwe_encrypt_coeff0(5 + i, sk, 9 + i, 19 + i) for i in range(2)])
         r = [ram.read(addr, keys), ram.read_prepare_write(addr, keys), ram.store(), ram.tree(0)]
         ram.write(w, addr, keys)
