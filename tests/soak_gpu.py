@@ -38,7 +38,7 @@ def main(seconds=120, seed=None):
     while time.time() < t_end:
         # batch sizes that select every launch decomposition: fine limb split (<= 10 ciphertexts), limb
         # parallel (<= 32), split by column (<= 128), fused
-        batch = int(rng.choice([1, 3, 4, 8, 10, 11, 16, 32, 64, 100, 128, 256, 300, 512]))
+        batch = int(rng.choice([1, 3, 4, 8, 10, 11, 16, 32, 33, 48, 64, 65, 100, 128, 256, 300, 512]))
         a = rng.integers(-(1 << 16), 1 << 16, size=(batch, glen), dtype=np.int64)
         sample = rng.choice(batch, size=min(batch, 3), replace=False)
         kind = int(rng.integers(0, 4))
