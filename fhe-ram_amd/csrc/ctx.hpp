@@ -115,6 +115,12 @@ struct fheram_ctx {
     //  memo_alone: arena A holds every local row after the packer levels in which it is alone (ram.rs:514; n steps),
     //              which ARE the first n steps of trace(ct_hi) in write_mid_step (ram.rs:616).
     int memo = 1;
+    //  tail: the dependent trace chain at the end of a read as ONE launch with in-kernel hand-offs (k_trace_tail);
+    //        FHERAM_TAIL=0: one launch pair per step as before;  FHERAM_TAIL=2: test hook, the launch gives up two steps before its end
+    //        and the fused fallback launch behind it does the work.
+    int tail = 1;
+    unsigned tail_seq = 0;
+    unsigned* d_tail_sync = nullptr;   // [8 groups][32] + abort generation
     bool memo_top = false;
     int memo_alone = 0;
     int32_t* d_trtop = nullptr;    // [ws]

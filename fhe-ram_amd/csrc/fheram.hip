@@ -96,6 +96,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->fine_split = (fs && fs[0] == '0') ? 0 : 1;
         const char* mm = getenv("FHERAM_MEMO");
         c->memo = (mm && mm[0] == '0') ? 0 : 1;
+        const char* tl = getenv("FHERAM_TAIL");
+        c->tail = (tl && tl[0] == '0') ? 0 : ((tl && tl[0] == '2') ? 2 : 1);
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* gr = getenv("FHERAM_GRAPH");
@@ -114,6 +116,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product_fine<4, 5>));
     LDSATTR((&k_ext_product_chain<3, 4>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
+    LDSATTR((&k_trace_tail<3, 4, 3>));
 #define LDSATTR_KS4(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
 #define LDSATTR_KS(M, SX, SK, SO) LDSATTR_KS4(M, SX, SK, SO); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);
@@ -159,6 +162,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_prep, (size_t)std::max(c->n_digits, c->max_digits) * fheram_ctx::GGSW * sizeof(double)));
     CCHK(hipMalloc(&c->d_ggsw_tmp, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     CCHK(hipMemset(c->d_tree, 0, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_tail_sync, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
+    CCHK(hipMemset(c->d_tail_sync, 0, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
 #undef CCHK
     *out = c;
     return FHERAM_OK;
@@ -179,7 +184,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -42,9 +42,24 @@ __device__ unsigned long long g_stamps[192];
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
+#ifndef FK_STAMP_STEP
+#define FK_STAMP_STEP 2
+#endif
+// k_trace_tail: every member of group 0, step FK_STAMP_STEP: g_stamps[stamp * 24 + member], 100 MHz real-time clock (the same on every CU)
+#define TSTAMP(i)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (threadIdx.x == 0 && s == FK_STAMP_STEP && g == 0) {                                    \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            g_stamps[(i) * 24 + m] = t_;                                                           \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMPZ(i) do { } while (0)
+#define TSTAMP(i) do { } while (0)
 #endif
 
 struct GlweRef {   // p + y*sy + x*sx  (int32 elements)
@@ -798,10 +813,13 @@ struct KsChainArgs {
     const double* key[CHAIN_MAX];
     int ginv[CHAIN_MAX];
     int n;
+    const unsigned* pred = nullptr;  // fallback launch behind k_trace_tail: runs only if *pred == pred_seq (that launch gave up)
+    unsigned pred_seq = 0;
 };
 template <int SX, int SK, int SO>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (ca.pred && __hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
     KsArgs ka = ca.base;
 #pragma unroll 1
     for (int i = 0; i < ca.n; i++) {
@@ -817,6 +835,255 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) 
         ka.a = ka.out;
         ka.rot_mul = 0;
         ka.rot_base = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_trace_tail: the dependent trace chain at the end of a read (ram.rs:457,540: n steps on word_size ciphertexts)
+// as ONE launch that keeps the fine limb split: 2*SK*SX workgroups per ciphertext, one forward and one inverse
+// transform each per step, then a normalisation phase, with TWO IN-KERNEL HAND-OFFS per step instead of two kernel
+// boundaries.  What makes the hand-off cheap (tools/xcd_barrier.hip: 1.1 us against 3 us for a kernel boundary and
+// 9-18 us for agent-scope fences): the workgroups of a ciphertext all sit on ONE XCD — block b runs on XCD b % 8
+// (round-robin placement), so group g = the blocks with b % 8 == g — and an XCD has one L2: a producer only has to
+// drain its stores (vmcnt 0; the L1 is write-through) and a consumer only has to bypass its own L1 (sc1 loads);
+// no L2 write-back or invalidate.  The placement is CHECKED, not assumed: every workgroup publishes its XCC id and
+// the group gives up unless they agree.  Every wait is bounded: a group that cannot meet (its workgroups are not
+// co-resident because another context holds the CUs, wrong placement) raises the abort word to this launch's
+// generation and leaves; the fused chain launch enqueued right behind (k_keyswitch_chain, predicated on that word)
+// then redoes the chain from the untouched source.  Results are the same either way (same per-coefficient arithmetic).
+//   grid (8 * 2*SK*SX): group g = b % 8 = ciphertext (x = g % gx, y = g / gx), member m = b / 8 = ((co*SK + (SK-1-j))*SX + r)
+//   sync: [group][32] words: arrivals, leavers, XCC mask;  sync[8*32] = abort generation
+// ---------------------------------------------------------------------------------------
+constexpr int TAIL_GROUPS = 8;
+constexpr int TAIL_SPIN_MAX = 1 << 14;   // x one L2 round trip (>= 0.3 us) >= 5 ms
+struct TailArgs {
+    GlweRef src, buf[2];             // step i writes buf[i & 1] (buf[0] must not be the source)
+    const double* key[CHAIN_MAX];
+    int ginv[CHAIN_MAX];
+    const double* tw;
+    double* big;                     // 2*SK*SX partial polynomials per ciphertext (BIG_STRIDE * SX doubles apart)
+    unsigned* sync;
+    unsigned seq;                    // generation of this launch (never 0)
+    int n, n_ct, gx;
+    int give_up_at;                  // test hook: member 5 of group 0 gives up at this step (-1: never)
+};
+__device__ __forceinline__ int xcc_id() {
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+__device__ __forceinline__ int ld_l2(const int32_t* p) { return __hip_atomic_load(const_cast<int32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_l2(const double* p) { return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// All G workgroups of a group meet; false = the group gave up (this workgroup must leave).  `flag` is an LDS word.
+__device__ __forceinline__ bool tail_barrier(unsigned* ctr, unsigned* abortp, unsigned seq, unsigned want, int* flag, bool check_xcc, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (int spin = 0; spin < TAIL_SPIN_MAX; spin++) {
+            if ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) { ok = 1; break; }
+            if ((spin & 15) == 15 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) break;
+        }
+        if (ok && check_xcc) ok = (__builtin_popcount(__hip_atomic_load(ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1);
+        if (ok && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) ok = 0;
+        if (!ok) __hip_atomic_store(abortp, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+// Two int32 per 8-byte L1-bypassing load (coefficients 2q, 2q+1 of one limb polynomial).
+__device__ __forceinline__ void ld_l2_pair(const int32_t* p, int& a, int& b) {
+    const long long v = __hip_atomic_load(reinterpret_cast<long long*>(const_cast<int32_t*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = (int)(v & 0xffffffffll);
+    b = (int)(v >> 32);
+}
+// Every consumer of an intermediate ciphertext of the chain wants x = rsh1(a) (the pre-step of the NEXT trace step),
+// never a itself: the normalisation phase of step s therefore writes rsh1 of its result (it holds all limbs of the
+// coefficient anyway) for s < n-1, and a workgroup of step s+1 loads ONE limb polynomial (16 KB) instead of three.
+template <int SX, int SK, int SO>
+__global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int G = 2 * SK * SX;
+    const int g = (int)blockIdx.x % TAIL_GROUPS, m = (int)blockIdx.x / TAIL_GROUPS;
+    if (g >= ta.n_ct) return;
+    const int tid = threadIdx.x;
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    int* mstage = reinterpret_cast<int*>(data);
+    int* bstage = mstage + N;
+    int* flag = reinterpret_cast<int*>(data + 2 * LDS_DATA);   // the third exchange buffer is not used here
+    unsigned* ctr = ta.sync + g * 32;
+    unsigned* abortp = ta.sync + TAIL_GROUPS * 32;
+    const int r = m % SX, zz = m / SX;
+    const int j = SK - 1 - zz % SK, co = zz / SK;
+    const bool adds_body = (r == 0 && co == 0 && j < SX);
+    const long ct = (long)(g / ta.gx);
+    const long cx = (long)(g % ta.gx);
+    double* bigg = ta.big + (long)g * BIG_STRIDE * SX;
+    OpRegs kop;
+    load_ops(kop, ta.key[0] + (long)((r * SK + j) * 2 + co) * N, tid);
+    if (tid == 0) {
+        __hip_atomic_fetch_or(ctr + 2, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // performed before this workgroup's first arrival is counted
+    }
+    load_twiddles(tw, ta.tw, tid);
+    unsigned epoch = 0;
+#pragma unroll 1
+    for (int s = 0; s < ta.n; s++) {
+        const GlweRef rin = (s == 0) ? ta.src : ta.buf[(s - 1) & 1];
+        const GlweRef rout = ta.buf[s & 1];
+        const int32_t* ap = rin.p + ct * rin.sy + cx * rin.sx;
+        int32_t* op = rout.p + ct * rout.sy + cx * rout.sx;
+        const int ginv = ta.ginv[s];
+        const bool stepped = (s > 0);          // the input already is rsh1(a)
+        const bool last = (s + 1 == ta.n);
+        TSTAMP(0);
+        // ---- fine phase: x = rsh1(a); partial[co][j][r] = INTT(NTT(phi_g(x.mask limb r)) . K[r][j][co]) (+ phi_g(x.body limb j))
+        // staging: thread t brings coefficients 8t .. 8t+7 (natural order) of the limb polynomials it needs
+        if (stepped) {
+            int v[E], w[E];
+#pragma unroll
+            for (int q = 0; q < E / 2; q++) ld_l2_pair(ap + glwe_off(r, 1) + E * tid + 2 * q, v[2 * q], v[2 * q + 1]);
+            if (adds_body) {
+#pragma unroll
+                for (int q = 0; q < E / 2; q++) ld_l2_pair(ap + glwe_off(j, 0) + E * tid + 2 * q, w[2 * q], w[2 * q + 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < E; k++) mstage[E * tid + k] = v[k];
+            if (adds_body) {
+#pragma unroll
+                for (int k = 0; k < E; k++) bstage[E * tid + k] = w[k];
+            }
+        } else {
+            // the source was written by an earlier launch: ordinary (16-byte) loads
+            int rm[SX][E], rb[SX][E];
+#pragma unroll
+            for (int q = 0; q < SX; q++)
+#pragma unroll
+                for (int h = 0; h < E / 4; h++) {
+                    const int4 v4 = *reinterpret_cast<const int4*>(ap + glwe_off(q, 1) + E * tid + 4 * h);
+                    rm[q][4 * h] = v4.x; rm[q][4 * h + 1] = v4.y; rm[q][4 * h + 2] = v4.z; rm[q][4 * h + 3] = v4.w;
+                }
+            if (adds_body) {
+#pragma unroll
+                for (int q = 0; q < SX; q++)
+#pragma unroll
+                    for (int h = 0; h < E / 4; h++) {
+                        const int4 v4 = *reinterpret_cast<const int4*>(ap + glwe_off(q, 0) + E * tid + 4 * h);
+                        rb[q][4 * h] = v4.x; rb[q][4 * h + 1] = v4.y; rb[q][4 * h + 2] = v4.z; rb[q][4 * h + 3] = v4.w;
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                int xi[SX], xm[SX];
+#pragma unroll
+                for (int q = 0; q < SX; q++) xi[q] = rm[q][k];
+                rsh1_coeff<SX>(xi, xm);
+                mstage[E * tid + k] = sel_limb(xm, r);
+            }
+            if (adds_body) {
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    int xi[SX], xb[SX];
+#pragma unroll
+                    for (int q = 0; q < SX; q++) xi[q] = rb[q][k];
+                    rsh1_coeff<SX>(xi, xb);
+                    bstage[E * tid + k] = sel_limb(xb, j);
+                }
+            }
+        }
+        __syncthreads();
+        TSTAMP(1);
+        double x[1][E];
+        int bodyv[E];
+        {
+            int sidx = (tid * ginv) & (2 * N - 1);
+            const int sstep = (T * ginv) & (2 * N - 1);
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                x[0][k] = (double)cneg(mstage[sidx & (N - 1)], sidx >= N);
+                bodyv[k] = adds_body ? cneg(bstage[sidx & (N - 1)], sidx >= N) : 0;
+                sidx = (sidx + sstep) & (2 * N - 1);
+            }
+        }
+        ntt_fwd<1>(x, tw, data, tid);        // starts with a barrier: every gather of the staged limbs is done
+        TSTAMP(2);
+        double acc[1][E];
+#pragma unroll
+        for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+        mac_regs(acc[0], x[0], kop);
+        if (!last) load_ops(kop, ta.key[s + 1] + (long)((r * SK + j) * 2 + co) * N, tid);   // arrives during the rest of the step
+        ntt_inv<1, false>(acc, tw, data, tid);
+        TSTAMP(3);
+        {
+            double* bgp = bigg + (long)((co * SK + j) * SX + r) * N;
+#pragma unroll
+            for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k] + (double)bodyv[k];
+        }
+        if (ta.give_up_at == s && g == 0 && m == 5) {
+            if (tid == 0) __hip_atomic_store(abortp, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        TSTAMP(4);
+        if (!tail_barrier(ctr, abortp, ta.seq, (++epoch) * G, flag, s == 0, tid)) break;
+        TSTAMP(5);
+        // ---- normalisation phase: one thread per (column, coefficient); same arithmetic as k_keyswitch_norm<KS_TRACE>
+        const int gid = m * T + tid;
+        if (gid < 2 * N) {
+            const int nco = gid / N, i = gid % N;
+            const double* bgp = bigg + (long)nco * SK * SX * N + i;
+            double v_[SK];
+#pragma unroll
+            for (int q = 0; q < SK; q++) {
+                v_[q] = ld_l2(bgp + (long)(q * SX) * N);
+#pragma unroll
+                for (int w = 1; w < SX; w++) v_[q] += ld_l2(bgp + (long)(q * SX + w) * N);   // exact: integers below 2^47
+            }
+            int raw[SX], xa[SX];
+#pragma unroll
+            for (int q = 0; q < SX; q++) raw[q] = ld_l2(ap + glwe_off(q, nco) + i);
+            if (stepped) {
+#pragma unroll
+                for (int q = 0; q < SX; q++) xa[q] = raw[q];
+            } else {
+                rsh1_coeff<SX>(raw, xa);
+            }
+            double carry = 0.0;
+            int d[SO], y[SO];
+#pragma unroll
+            for (int q = SK - 1; q >= 0; q--) {
+                double v = v_[q];
+                if (q < SX) v += (double)xa[q < SX ? q : 0];
+                v += carry;
+                const double cy = carry_of(v);
+                carry = cy;
+                if (q < SO) d[q < SO ? q : 0] = (int)digit_of(v, cy);
+            }
+            if (last) {
+#pragma unroll
+                for (int q = 0; q < SO; q++) y[q] = d[q];
+            } else {
+                rsh1_coeff<SO>(d, y);
+            }
+#pragma unroll
+            for (int q = 0; q < SO; q++) op[glwe_off(q, nco) + i] = y[q];
+        }
+        TSTAMP(6);
+        if (!last && !tail_barrier(ctr, abortp, ta.seq, (++epoch) * G, flag, false, tid)) break;
+        TSTAMP(7);
+    }
+    // the last workgroup of the group to leave (every one passes here exactly once, given up or not) rewinds the
+    // group's words for the next launch: nobody can still be waiting on them
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(G - 1)) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

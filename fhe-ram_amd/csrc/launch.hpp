@@ -156,11 +156,38 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
     for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
     hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
 }
+// The latency-bound end of the path (at most 8 ciphertexts, one per XCD): n trace steps as ONE launch with in-kernel
+// hand-offs (k_trace_tail), followed by the fused chain launch that only runs if that one gave up.
+bool use_tail(const fheram_ctx* c, int n, int gx, int gy) {
+    return c->tail && c->limb_split && c->fine_split && n >= 2 && n <= CHAIN_MAX && (long)gx * gy <= TAIL_GROUPS &&
+           c->cus >= TAIL_GROUPS * 32 &&     // the whole chip (8 XCDs x 32 CUs): a partition could not hold the groups side by side
+           !(c->use_graph && !c->profile);   // a captured launch would replay its generation number
+}
+void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy) {
+    ProfScope ps(c, "keyswitch", (uint64_t)gx * gy, n);
+    ProfScope pt(c, "keyswitch_tail_launch", (uint64_t)gx * gy * n, 1);
+    TailArgs ta;
+    ta.src = src; ta.buf[0] = b[0]; ta.buf[1] = b[1]; ta.tw = c->d_tw; ta.big = big_of(c); ta.sync = c->d_tail_sync;
+    if (++c->tail_seq == 0) ++c->tail_seq;
+    ta.seq = c->tail_seq; ta.n = n; ta.n_ct = gx * gy; ta.gx = gx; ta.give_up_at = (c->tail == 2) ? n - 2 : -1;   // late: every buffer but the source has been overwritten by then
+    KsChainArgs ca;
+    ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, 0, 0);
+    ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
+    ca.pred = c->d_tail_sync + TAIL_GROUPS * 32; ca.pred_seq = ta.seq;
+    for (int i = 0; i < n; i++) { ta.key[i] = ca.key[i] = trace_key(c, start + i); ta.ginv[i] = ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
+    hipLaunchKernelGGL((k_trace_tail<3, 4, 3>), dim3(TAIL_GROUPS * 2 * 4 * 3), dim3(T), LDS_BYTES, c->cur, ta);
+    hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+}
 // GLWE::trace(start, end): step i = rsh(1) then a += phi_{g_i}(KS(a)).
 // The first step may read its input rotated by X^-(x*rot_mul) (write path, ram.rs:621,629).
 void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start, int end, int gx, int gy, int rot_mul = 0, int rot_base = 0) {
     if (gx <= 0 || gy <= 0) return;
     const int n = end - start;
+    if (rot_mul == 0 && rot_base == 0 && use_tail(c, n, gx, gy)) {
+        // the source must survive the launch (its fallback restarts from it): out of place only
+        GlweRef b[2];
+        if (chain_bufs(n, src, dst, tmp, b) && !same(b[1], src)) { launch_trace_tail(c, src, b, start, n, gx, gy); return; }
+    }
     if (use_chain(c, n, gx, gy, 4) && !use_fine_split(c, gx, gy, 2 * 4 * 3)) {
         GlweRef b[2];
         if (chain_bufs(n, src, dst, tmp, b)) { launch_trace_chain(c, src, b, start, n, gx, gy, rot_mul, rot_base); return; }

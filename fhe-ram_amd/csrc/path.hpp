@@ -95,7 +95,7 @@ int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweR
 int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t* gathered, GlweRef pk) {
     const long G = (long)fheram_ctx::GLWE;
     const int ws = c->ws;
-    GlweRef res = ref(c->d_res, G, 0), tmp = ref(c->d_tmp, G, 0), tree = ref(c->d_tree, G, 0);
+    GlweRef tmp = ref(c->d_tmp, G, 0), tree = ref(c->d_tree, G, 0);
     GlweRef last = pk;
     if (c->n2 == 2) {
         if (gathered) {
@@ -112,8 +112,9 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
             ep_chain(c, pk, tree, tmp, prep_of(c, 1), d1, 1, ws);                         // ram.rs:525-527 + 502-504 (i = 1): tree[0] <- rotated packed row
             last = tree;                                                              // ram.rs:535 (res <- tree[0])
         } else {
-            ep_chain(c, pk, res, tmp, prep_of(c, 1), d1, 1, ws);                          // ram.rs:454
-            last = res;
+            GlweRef tmp2 = ref(c->d_tmp2, G, 0);
+            ep_chain(c, pk, tmp2, tmp, prep_of(c, 1), d1, 1, ws);                         // ram.rs:454 (not into res: the trace below runs out of place)
+            last = tmp2;
         }
     }                                                                                 // n2 == 1: res <- packed row (ram.rs:452 / 537)
     // read_prepare_write: the result is also what write_first_step computes first (trace of the same ciphertext,
