@@ -289,6 +289,7 @@ def main():
     per_op = [step() for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
+    tail = ram.tail_stats()       # single-launch trace chains so far (warm-up + timed steps) and how many fell back
     # Kernel-class durations for the roofline: the same K steps once more, now with every launch
     # bracketed by HIP events on its stream.  Those events break back-to-back submission and add
     # ~20 % to a step, so they are kept OUT of the timed region above.
@@ -366,6 +367,8 @@ def main():
                                    "write": a_write / write_ms / 1e6},
         "reference_published": {"read_ms": 450, "write_ms": 1200, "hw": "i9-12900K single thread (README.md:36), 2^18 entries",
                                 "speedup_read": 450.0 / read_ms, "speedup_write": 1200.0 / write_ms},
+        "trace_tail": dict(tail, note="trace chains at the end of a read run as one launch with in-kernel hand-offs; `fallbacks` of them "
+                                      "gave up (CUs not available side by side) and were redone by the fused launch behind them"),
         "device": ram.device_info(),
     }
     if boundary is not None:

@@ -107,6 +107,7 @@ _SYMBOLS = [
     ("fheram_timer_end", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("fheram_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("fheram_profile_get", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    ("fheram_tail_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fheram_profile_reset", C.c_int, [C.c_void_p]),
     ("fheram_bench_external_product", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("fheram_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
@@ -736,6 +737,12 @@ class Ram:
         a, b, ms = C.c_uint64(), C.c_uint64(), C.c_double()
         self._chk(library().fheram_profile_get(self._h, cls.encode(), C.byref(a), C.byref(b), C.byref(ms)))
         return {"launches": int(a.value), "blocks": int(b.value), "ms": float(ms.value)}
+
+    def tail_stats(self):
+        """single-launch trace chains since the context was created, and how many of them fell back (fheram_tail_stats)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(library().fheram_tail_stats(self._h, C.byref(a), C.byref(b)))
+        return {"launches": int(a.value), "fallbacks": int(b.value)}
 
     def bench_external_product(self, batch: int, iters: int) -> float:
         """ms for a dependent chain of `iters` launches of `batch` GLWE x GGSW products (BASELINE.json configs[1])"""

@@ -120,7 +120,8 @@ struct fheram_ctx {
     //        and the fused fallback launch behind it does the work.
     int tail = 1;
     unsigned tail_seq = 0;
-    unsigned* d_tail_sync = nullptr;   // [8 groups][32] + abort generation
+    uint64_t tail_launches = 0;
+    unsigned* d_tail_sync = nullptr;   // [8 groups][32] + abort generation, fallbacks taken
     bool memo_top = false;
     int memo_alone = 0;
     int32_t* d_trtop = nullptr;    // [ws]

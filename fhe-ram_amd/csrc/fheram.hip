@@ -590,6 +590,16 @@ int fheram_profile_get(fheram_ctx* c, const char* cls, uint64_t* launches, uint6
     if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
     return FHERAM_OK;
 }
+int fheram_tail_stats(fheram_ctx* c, uint64_t* launches, uint64_t* fallbacks) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned fb = 0;
+    HIPCHK(c, hipMemcpyAsync(&fb, c->d_tail_sync + TAIL_GROUPS * 32 + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (launches) *launches = c->tail_launches;
+    if (fallbacks) *fallbacks = fb;
+    return FHERAM_OK;
+}
 #ifdef FK_STAMP
 int fheram_debug_ntt_probe(fheram_ctx* c, int blocks) {
     hipSetDevice(c->device);

@@ -819,7 +819,10 @@ struct KsChainArgs {
 template <int SX, int SK, int SO>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (ca.pred && __hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
+    if (ca.pred) {
+        if (__hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(const_cast<unsigned*>(ca.pred) + 1, 1u);   // fallbacks taken (fheram_tail_stats)
+    }
     KsArgs ka = ca.base;
 #pragma unroll 1
     for (int i = 0; i < ca.n; i++) {

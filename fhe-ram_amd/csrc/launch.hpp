@@ -169,6 +169,7 @@ void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int st
     TailArgs ta;
     ta.src = src; ta.buf[0] = b[0]; ta.buf[1] = b[1]; ta.tw = c->d_tw; ta.big = big_of(c); ta.sync = c->d_tail_sync;
     if (++c->tail_seq == 0) ++c->tail_seq;
+    c->tail_launches++;
     ta.seq = c->tail_seq; ta.n = n; ta.n_ct = gx * gy; ta.gx = gx; ta.give_up_at = (c->tail == 2) ? n - 2 : -1;   // late: every buffer but the source has been overwritten by then
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, 0, 0);

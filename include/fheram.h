@@ -243,6 +243,11 @@ int fheram_timer_end(fheram_ctx* ctx, float* elapsed_ms);
 int fheram_profile_enable(fheram_ctx* ctx, int on);
 int fheram_profile_get(fheram_ctx* ctx, const char* kernel_class, uint64_t* launches, uint64_t* blocks, double* total_ms);
 int fheram_profile_reset(fheram_ctx* ctx);
+/* The trace chain at the end of a read (ram.rs:457,540) runs as one launch whose workgroups hand over inside the
+ * kernel; a launch that could not assemble its workgroup groups (CUs held by another context) gives up and the fused
+ * launch enqueued behind it redoes the chain, with the same result.  launches = such launches since the context was
+ * created, fallbacks = how many of them gave up.  Waits for the context's stream. */
+int fheram_tail_stats(fheram_ctx* ctx, uint64_t* launches, uint64_t* fallbacks);
 /* BASELINE.json configs[1]: one GLWE x GGSW external product at N = 4096 on device-resident synthetic
  * operands (normalised limbs; the work is data independent).  Runs `iters` launches of `batch` products
  * back to back on the context's stream, each launch consuming the previous one's output (a dependent

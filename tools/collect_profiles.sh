@@ -2,7 +2,7 @@ set -x
 # Collects the round's profile set on an MI355X box (run through gpurun); summaries land in gpurun_out/r2q, from where
 # the ones to be judged are copied into profiles/.  Counters are collected in separate passes (FETCH_SIZE, WRITE_SIZE, SQ).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r2q; mkdir -p $O
-for t in fetch_calib xcd_handoff; do [ -x $R/tools/$t ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/$t $R/tools/$t.hip; done
+for t in fetch_calib xcd_handoff xcd_barrier; do [ -x $R/tools/$t ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/$t $R/tools/$t.hip; done
 [ -x $R/tools/ntt_bench ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I$R/fhe-ram_amd/csrc -o $R/tools/ntt_bench $R/tools/ntt_bench.hip
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-boundary"
@@ -15,6 +15,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/lds -- $B > $O/lds.json 2> $O/lds.err
 cd $R
 python tools/trace_summary.py $O/stats 40 > $O/kernel_trace_by_grid.txt
+python tools/trace_timeline.py $O/stats 0 100000 | tail -330 > $O/timeline.txt
 cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv
 python tools/pmc_hbm.py $O/cfetch $O/cwrite $O/fetch $O/write > $O/pmc_hbm_traffic.json
 python tools/pmc_sq_summary.py pmc_sq=$O/sq pmc_lds=$O/lds > $O/pmc_sq_summary.txt
@@ -26,3 +27,4 @@ python bench.py --log-max-addr 21 --steps 5 --no-cpu-baseline > $O/bench_2_21.js
 python bench.py --workload ep > $O/bench_ep.json 2> $O/bench_ep.err
 ./tools/ntt_bench > $O/ntt_bench.txt 2>&1
 ./tools/xcd_handoff > $O/xcd_handoff.txt 2>&1
+./tools/xcd_barrier > $O/xcd_barrier.txt 2>&1
