@@ -116,11 +116,18 @@ struct fheram_ctx {
     //              which ARE the first n steps of trace(ct_hi) in write_mid_step (ram.rs:616).
     int memo = 1;
     //  tail: the dependent trace chain at the end of a read as ONE launch with in-kernel hand-offs (k_trace_tail);
-    //        FHERAM_TAIL=0: one launch pair per step as before;  FHERAM_TAIL=2: test hook, the launch gives up two steps before its end
+    //        FHERAM_TAIL=0: one launch pair per step as before;  FHERAM_TAIL=2 / 3: test hooks, the launch gives up two steps before its end
     //        and the fused fallback launch behind it does the work.
     int tail = 1;
+    int tail_test = 0;                 // FHERAM_TAIL=2 / 3: every launch gives up late; 3 keeps the watch below active
     unsigned tail_seq = 0;
     uint64_t tail_launches = 0;
+    //  watch: the fallback launch mirrors its count into a pinned host word; if more than a quarter of the last 64
+    //  single-launch chains gave up (a GPU shared so heavily, or partitioned so, that their groups do not fit side by
+    //  side: each such launch waited ~5 ms first), the context goes back to one launch pair per step for good.
+    unsigned* h_tail_fb = nullptr;     // pinned, device-visible
+    unsigned tail_fb_mark = 0;
+    uint64_t tail_launch_mark = 0;
     unsigned* d_tail_sync = nullptr;   // [8 groups][32] + abort generation, fallbacks taken
     bool memo_top = false;
     int memo_alone = 0;

@@ -97,7 +97,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         const char* mm = getenv("FHERAM_MEMO");
         c->memo = (mm && mm[0] == '0') ? 0 : 1;
         const char* tl = getenv("FHERAM_TAIL");
-        c->tail = (tl && tl[0] == '0') ? 0 : ((tl && tl[0] == '2') ? 2 : 1);
+        c->tail = (tl && tl[0] == '0') ? 0 : 1;
+        c->tail_test = (tl && tl[0] == '2') ? 1 : ((tl && tl[0] == '3') ? 2 : 0);
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* gr = getenv("FHERAM_GRAPH");
@@ -164,6 +165,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMemset(c->d_tree, 0, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tail_sync, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     CCHK(hipMemset(c->d_tail_sync, 0, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
+    CCHK(hipHostMalloc((void**)&c->h_tail_fb, 64, hipHostMallocDefault));
+    *c->h_tail_fb = 0;
 #undef CCHK
     *out = c;
     return FHERAM_OK;
@@ -186,6 +189,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
     void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync};
     for (void* b : bufs) if (b) hipFree(b);
+    if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

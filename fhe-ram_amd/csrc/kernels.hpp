@@ -815,13 +815,17 @@ struct KsChainArgs {
     int n;
     const unsigned* pred = nullptr;  // fallback launch behind k_trace_tail: runs only if *pred == pred_seq (that launch gave up)
     unsigned pred_seq = 0;
+    unsigned* host_count = nullptr;  // pinned host word that mirrors the number of fallbacks taken (read by the host without a sync)
 };
 template <int SX, int SK, int SO>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.pred) {
         if (__hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(const_cast<unsigned*>(ca.pred) + 1, 1u);   // fallbacks taken (fheram_tail_stats)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            const unsigned taken = atomicAdd(const_cast<unsigned*>(ca.pred) + 1, 1u) + 1u;   // fallbacks taken (fheram_tail_stats)
+            if (ca.host_count) __hip_atomic_store(ca.host_count, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     KsArgs ka = ca.base;
 #pragma unroll 1

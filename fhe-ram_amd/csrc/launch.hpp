@@ -170,11 +170,17 @@ void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int st
     ta.src = src; ta.buf[0] = b[0]; ta.buf[1] = b[1]; ta.tw = c->d_tw; ta.big = big_of(c); ta.sync = c->d_tail_sync;
     if (++c->tail_seq == 0) ++c->tail_seq;
     c->tail_launches++;
-    ta.seq = c->tail_seq; ta.n = n; ta.n_ct = gx * gy; ta.gx = gx; ta.give_up_at = (c->tail == 2) ? n - 2 : -1;   // late: every buffer but the source has been overwritten by then
+    if (c->tail_test != 1 && c->tail_launches - c->tail_launch_mark >= 64) {
+        const unsigned fb = *(volatile unsigned*)c->h_tail_fb;
+        if (fb - c->tail_fb_mark > 16) c->tail = 0;      // takes effect from the next chain on
+        c->tail_fb_mark = fb;
+        c->tail_launch_mark = c->tail_launches;
+    }
+    ta.seq = c->tail_seq; ta.n = n; ta.n_ct = gx * gy; ta.gx = gx; ta.give_up_at = c->tail_test ? n - 2 : -1;   // late: every buffer but the source has been overwritten by then
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, 0, 0);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
-    ca.pred = c->d_tail_sync + TAIL_GROUPS * 32; ca.pred_seq = ta.seq;
+    ca.pred = c->d_tail_sync + TAIL_GROUPS * 32; ca.pred_seq = ta.seq; ca.host_count = c->h_tail_fb;
     for (int i = 0; i < n; i++) { ta.key[i] = ca.key[i] = trace_key(c, start + i); ta.ginv[i] = ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
     hipLaunchKernelGGL((k_trace_tail<3, 4, 3>), dim3(TAIL_GROUPS * 2 * 4 * 3), dim3(T), LDS_BYTES, c->cur, ta);
     hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
