@@ -56,6 +56,7 @@ __global__ __launch_bounds__(T) void k_rounds(double* buf, unsigned* counters, i
             bad += (v != expect0 + k);
         }
         // second barrier of a round (the consumer side must be done before the producer overwrites): counted in the cost
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every load of this wave has returned before it says so
         __syncthreads();
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
