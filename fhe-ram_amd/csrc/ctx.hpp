@@ -121,6 +121,7 @@ struct fheram_ctx {
     int tail = 1;
     int tail_test = 0;                 // FHERAM_TAIL=2 / 3: every launch gives up late; 3 keeps the watch below active
     unsigned tail_seq = 0;
+    int tail_xoff = 0;                 // first XCD of this context's groups (0 or 4, alternating over contexts and processes)
     uint64_t tail_launches = 0;
     //  watch: the fallback launch mirrors its count into a pinned host word; if more than a quarter of the last 64
     //  single-launch chains gave up (a GPU shared so heavily, or partitioned so, that their groups do not fit side by

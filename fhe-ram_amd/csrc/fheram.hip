@@ -2,6 +2,8 @@
 // Host orchestration of Ram::read / read_prepare_write / write (reference: src/ram.rs) over the
 // fused HIP kernels in kernels.hpp.  No CPU compute path exists here: every ciphertext
 // operation is a kernel launch, and a missing GPU is a hard error.
+#include <unistd.h>
+#include <atomic>
 #include "path.hpp"
 
 extern "C" {
@@ -98,6 +100,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->memo = (mm && mm[0] == '0') ? 0 : 1;
         const char* tl = getenv("FHERAM_TAIL");
         c->tail = (tl && tl[0] == '0') ? 0 : 1;
+        static std::atomic<int> serial{0};
+        c->tail_xoff = ((serial++ + (int)getpid()) & 1) * (TAIL_GROUPS / 2);
         c->tail_test = (tl && tl[0] == '2') ? 1 : ((tl && tl[0] == '3') ? 2 : 0);
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;

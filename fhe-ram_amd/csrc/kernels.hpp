@@ -858,7 +858,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) 
 // co-resident because another context holds the CUs, wrong placement) raises the abort word to this launch's
 // generation and leaves; the fused chain launch enqueued right behind (k_keyswitch_chain, predicated on that word)
 // then redoes the chain from the untouched source.  Results are the same either way (same per-coefficient arithmetic).
-//   grid (8 * 2*SK*SX): group g = b % 8 = ciphertext (x = g % gx, y = g / gx), member m = b / 8 = ((co*SK + (SK-1-j))*SX + r)
+//   grid (8 * 2*SK*SX): group g = (b - xoff) % 8 = ciphertext (x = g % gx, y = g / gx), member m = b / 8 = ((co*SK + (SK-1-j))*SX + r)
 //   sync: [group][32] words: arrivals, leavers, XCC mask;  sync[8*32] = abort generation
 // ---------------------------------------------------------------------------------------
 constexpr int TAIL_GROUPS = 8;
@@ -872,6 +872,7 @@ struct TailArgs {
     unsigned* sync;
     unsigned seq;                    // generation of this launch (never 0)
     int n, n_ct, gx;
+    int xoff;                        // group g sits on the blocks with (b + 8 - xoff) % 8 == g: contexts that share a GPU start on different XCDs
     int give_up_at;                  // test hook: member 5 of group 0 gives up at this step (-1: never)
 };
 __device__ __forceinline__ int xcc_id() {
@@ -913,7 +914,7 @@ template <int SX, int SK, int SO>
 __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int G = 2 * SK * SX;
-    const int g = (int)blockIdx.x % TAIL_GROUPS, m = (int)blockIdx.x / TAIL_GROUPS;
+    const int g = ((int)blockIdx.x + TAIL_GROUPS - ta.xoff) % TAIL_GROUPS, m = (int)blockIdx.x / TAIL_GROUPS;
     if (g >= ta.n_ct) return;
     const int tid = threadIdx.x;
     double* tw = lds;

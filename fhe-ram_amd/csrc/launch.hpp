@@ -176,7 +176,7 @@ void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int st
         c->tail_fb_mark = fb;
         c->tail_launch_mark = c->tail_launches;
     }
-    ta.seq = c->tail_seq; ta.n = n; ta.n_ct = gx * gy; ta.gx = gx; ta.give_up_at = c->tail_test ? n - 2 : -1;   // late: every buffer but the source has been overwritten by then
+    ta.seq = c->tail_seq; ta.n = n; ta.n_ct = gx * gy; ta.gx = gx; ta.xoff = c->tail_xoff; ta.give_up_at = c->tail_test ? n - 2 : -1;   // late: every buffer but the source has been overwritten by then
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, 0, 0);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
