@@ -20,3 +20,12 @@ def test_soak_whole_ram_flows_over_random_shapes(po):
     bit-identical to the oracle's."""
     import soak_flow_gpu
     assert soak_flow_gpu.main(seconds=25, seed=20261004) >= 2
+
+
+def test_soak_single_launch_trace_chain(po):
+    """tests/soak_tail_gpu.py for a bounded time: random batches of 1..8 ciphertexts through random trace ranges in ONE
+    launch each (in-kernel hand-offs), three times each (must reproduce itself) and against the oracle, while another
+    host thread fills the chip from a second context."""
+    import soak_tail_gpu
+    rounds, st = soak_tail_gpu.main(seconds=15, seed=20261005)
+    assert rounds >= 5 and st["launches"] >= 3 * rounds and st["fallbacks"] <= st["launches"]
