@@ -184,8 +184,8 @@ def bench_ep(pkg, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["ram", "ep"], default="ram",
                     help="ram = Ram::read / read_prepare_write / write (BASELINE.json configs[2..4], default); "
                          "ep = single external-product microbenchmark (configs[1])")
@@ -422,13 +422,17 @@ def main():
                                      "ms_per_step_instrumented": instr_elapsed * 1e3 / args.steps}
 
     if not args.no_cpu_baseline and world == 1 and mode == "single":   # reported baseline: rank 0 at N = 1 only
-        r, q, w = cpu_baseline(max_addr, 1, 99, 1)
-        # the sample is 1 of `ws` sub-RAMs: scale by ws (prepare_inv is shared, <1 % of a write)
-        cpu_step_s = ws * (r + q + w)
-        out["cpu_baseline"] = {"value": 2.0 / cpu_step_s, "unit": "RAM ops/s", "cores": 1, "kind": "port",
-                               "sample": f"oracle (C++ exact-integer restatement), 1 of {ws} sub-RAMs of the 2^{args.log_max_addr} RAM: "
-                                         f"read {r:.2f}s + read_prepare_write {q:.2f}s + write {w:.2f}s, scaled x{ws}",
-                               "read_ms": ws * r * 1e3, "read_prepare_write_ms": ws * q * 1e3, "write_ms": ws * w * 1e3,
+        # bounded sample (~10 s of CPU work at 2^18): the whole RAM, one step; beyond 2^18 one of the `ws` sub-RAMs, scaled by
+        # ws (the reference processes them one after the other, ram.rs:187-190; prepare_inv is shared, <1 % of a write)
+        whole = max_addr * ws <= (1 << 20)
+        k = 1 if whole else ws
+        r, q, w = cpu_baseline(max_addr, ws if whole else 1, 99, 1)
+        out["cpu_baseline"] = {"value": 2.0 / (k * (r + q + w)), "unit": "RAM ops/s", "cores": 1, "kind": "port",
+                               "sample": "oracle (C++ exact-integer restatement), single thread, "
+                                         + (f"the whole 2^{args.log_max_addr} x {ws}-byte RAM, one step: " if whole else
+                                            f"1 of {ws} sub-RAMs of the 2^{args.log_max_addr} RAM, scaled x{ws}: ")
+                                         + f"read {r:.2f}s + read_prepare_write {q:.2f}s + write {w:.2f}s",
+                               "read_ms": k * r * 1e3, "read_prepare_write_ms": k * q * 1e3, "write_ms": k * w * 1e3,
                                "host_cpu": host_cpu()}
         cores = host_cores()
         r, q, w = cpu_baseline(max_addr, ws, 99, cores)
