@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,8 @@ struct ProfCls {
 };
 
 }  // namespace
+
+inline uint64_t next_addr_id() { static std::atomic<uint64_t> n{0}; return ++n; }
 
 struct fheram_ctx {
     fheram_params p;
@@ -130,6 +133,16 @@ struct fheram_ctx {
     unsigned tail_fb_mark = 0;
     uint64_t tail_launch_mark = 0;
     unsigned* d_tail_sync = nullptr;   // [8 groups][32] + abort generation, fallbacks taken
+    //  inv_id[ci]: d_prep_inv holds the prepared INVERSE digits of coordinate ci of the address with that id
+    //              (CoordinatePrepared::prepare_inv, ram.rs:260-271,278-289): read_prepare_write — which is told the
+    //              address the write will use — starts them on the (low-priority) side stream next to its trace chain,
+    //              which is one launch holding 24 CUs on half of the XCDs: the rest of the chip is idle then.  A write
+    //              with another address, or after new keys, computes them itself.  FHERAM_PRE_INV=0: always.
+    int pre_inv = 1;
+    uint64_t inv_id[2] = {0, 0};
+    double* d_prep_inv = nullptr;  // [n_digits] prepared GGSW
+    int32_t* d_ggsw_inv = nullptr; // [n_digits] std GGSW: the inversion result on its way there (own scratch: runs beside anything)
+    hipEvent_t ev_inv[2] = {nullptr, nullptr};
     bool memo_top = false;
     int memo_alone = 0;
     int32_t* d_trtop = nullptr;    // [ws]
@@ -151,6 +164,7 @@ struct fheram_addr {
     int32_t* d_ggsw;   // [n_digits] std-form GGSW, int32
     int n_digits;
     int device;
+    uint64_t id = next_addr_id();   // never reused (a freed address may be followed by another one at the same pointer)
     hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // captured launch sequences: read, read_prepare_write, write
 };
 

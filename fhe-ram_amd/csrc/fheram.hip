@@ -83,7 +83,11 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     } while (0)
     CCHK(hipSetDevice(device));
     CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {   // side stream at the lowest priority: when both streams have a launch ready, the main stream's goes first
+        int lo = 0, hi = 0;
+        CCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        CCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+    }
     c->cur = c->stream;
     CCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -98,6 +102,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->fine_split = (fs && fs[0] == '0') ? 0 : 1;
         const char* mm = getenv("FHERAM_MEMO");
         c->memo = (mm && mm[0] == '0') ? 0 : 1;
+        const char* pi = getenv("FHERAM_PRE_INV");
+        c->pre_inv = (c->memo && !(pi && pi[0] == '0')) ? 1 : 0;
         const char* tl = getenv("FHERAM_TAIL");
         c->tail = (tl && tl[0] == '0') ? 0 : 1;
         static std::atomic<int> serial{0};
@@ -167,6 +173,9 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_prep, (size_t)std::max(c->n_digits, c->max_digits) * fheram_ctx::GGSW * sizeof(double)));
     CCHK(hipMalloc(&c->d_ggsw_tmp, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     CCHK(hipMemset(c->d_tree, 0, (size_t)c->ws * G * sizeof(int32_t)));
+    CCHK(hipMalloc(&c->d_prep_inv, (size_t)c->n_digits * fheram_ctx::GGSW * sizeof(double)));
+    CCHK(hipMalloc(&c->d_ggsw_inv, (size_t)c->n_digits * fheram_ctx::GGSW * sizeof(int32_t)));
+    for (int i = 0; i < 2; i++) CCHK(hipEventCreateWithFlags(&c->ev_inv[i], hipEventDisableTiming));
     CCHK(hipMalloc(&c->d_tail_sync, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     CCHK(hipMemset(c->d_tail_sync, 0, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     CCHK(hipHostMalloc((void**)&c->h_tail_fb, 64, hipHostMallocDefault));
@@ -184,6 +193,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     prof_collect(c);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    for (int i = 0; i < 2; i++) if (c->ev_inv[i]) hipEventDestroy(c->ev_inv[i]);
     if (c->ev_xout) hipEventDestroy(c->ev_xout);
     if (c->ev_xin) hipEventDestroy(c->ev_xin);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -191,7 +201,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -237,6 +247,7 @@ int fheram_keys_load(fheram_ctx* c, const int64_t* gal_els, int n_gal, const int
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
     c->keys_loaded = true;
+    c->inv_id[0] = c->inv_id[1] = 0;   // inverse digits prepared with the previous keys are void
     return FHERAM_OK;
 }
 

@@ -286,10 +286,35 @@ void ggsw_inverse(fheram_ctx* c, const int32_t* in, int32_t* tmp, int d) {
     KsArgs kt = ks_args(c, ref(tmp, (long)fheram_ctx::GGSW, 2 * g4), ref(tmp, 0, 0), ref(tmp + g4, (long)fheram_ctx::GGSW, 2 * g4), c->d_tsk, 1);
     launch_ks<KS_TENSOR, 4, 5, 4>(c, kt, fheram_ctx::DNUM_CT, d);
 }
+double* prep_inv_of(const fheram_ctx* c, int ci) { return c->d_prep_inv + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW; }
 void coordinate_prepare_inv(fheram_ctx* c, const fheram_addr* addr, int ci, int32_t* tmp, double* prep) {
     const int d = (int)c->base2d[ci].size();
     ggsw_inverse(c, addr->d_ggsw + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, tmp, d);
     launch_prepare(c, tmp, prep, d * (int)(fheram_ctx::GGSW / N));
 }
+
+// Under FHERAM_GRAPH=1 the enqueue functions run inside a stream capture: forked work has to be joined before the
+// capture ends, and an event recorded inside one captured op cannot be waited on from another.
+bool capturing(const fheram_ctx* c) { return c->use_graph && !c->profile; }
+// read_prepare_write: start the inverse digits of coordinate ci on the side stream (they depend on the address and the
+// keys only), behind everything enqueued on the main stream so far; Ram::write picks them up through ev_inv[ci].
+// fork == false: behind what the side stream already holds (the other coordinate): one event record on the main stream
+// per op, not two (a record between two dependent launches delays the second by ~13 us).
+// (Starting the side work from a signal word the trace chain's launch writes when its workgroups are placed —
+// hipStreamWaitValue32, no event on the main stream — was measured: the command processor polling that word for the
+// ~600 us until then slows every dispatch of the main stream, read_prepare_write 0.78 -> 0.95 ms at 2^18.)
+void precompute_inverse(fheram_ctx* c, const fheram_addr* addr, int ci, bool fork) {
+    if (fork) {
+        hipEventRecord(c->ev_fork, c->stream);
+        hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+    }
+    hipStream_t keep = c->cur;
+    c->cur = c->stream2;
+    coordinate_prepare_inv(c, addr, ci, c->d_ggsw_inv + (size_t)coord_first_digit(c, ci) * fheram_ctx::GGSW, prep_inv_of(c, ci));
+    hipEventRecord(c->ev_inv[ci], c->stream2);
+    c->cur = keep;
+    c->inv_id[ci] = addr->id;
+}
+void wait_inverse(fheram_ctx* c, hipStream_t s, int ci) { if (!capturing(c)) hipStreamWaitEvent(s, c->ev_inv[ci], 0); }
 
 }  // namespace

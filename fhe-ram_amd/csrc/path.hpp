@@ -31,7 +31,8 @@ int run_op(fheram_ctx* c, const fheram_addr* addr, int which, F&& enqueue) {
         c->memo_top = c->memo != 0;
         c->d_last_res = c->memo_top ? c->d_trtop : c->d_res;
         c->memo_alone = (c->memo && c->n2 == 2 && L0 > 0) ? L0 : 0;
-    } else { c->memo_top = false; c->memo_alone = 0; c->side_begun = false; c->tree_rotate_pending = false; }
+        if (c->pre_inv) for (int ci = 0; ci < c->n2; ci++) c->inv_id[ci] = addr->id;
+    } else { c->memo_top = false; c->memo_alone = 0; c->side_begun = false; c->tree_rotate_pending = false; c->inv_id[0] = c->inv_id[1] = 0; }
     c->prep1_ready = false;
     return FHERAM_OK;
 }
@@ -119,6 +120,10 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
     }                                                                                 // n2 == 1: res <- packed row (ram.rs:452 / 537)
     // read_prepare_write: the result is also what write_first_step computes first (trace of the same ciphertext,
     // ram.rs:571-572): it lands in d_trtop, which no read overwrites, and stays there for the write
+    // the write's inverse digits, next to the trace chain below (one launch on half of the XCDs; the side stream has the
+    // lowest priority, so that launch is placed first)
+    if (prepare_write && c->pre_inv)
+        for (int ci = c->n2 - 1; ci >= 0; ci--) precompute_inverse(c, addr, ci, ci == c->n2 - 1);   // coordinate 1 first: the write's head needs it first
     c->memo_top = prepare_write && c->memo;
     c->d_last_res = c->memo_top ? c->d_trtop : c->d_res;
     trace_steps(c, last, ref(c->d_last_res, G, 0), tmp, 0, LOGN, 1, ws);              // ram.rs:457 / 540
@@ -129,6 +134,8 @@ int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
     int rc = read_local(c, addr, prepare_write, &packed, false);
     if (rc != FHERAM_OK) return rc;
     rc = read_top(c, addr, prepare_write, nullptr, packed);
+    if (prepare_write && c->pre_inv && capturing(c))                                  // a capture ends with every fork joined
+        for (int ci = 0; ci < c->n2; ci++) hipStreamWaitEvent(c->stream, c->ev_inv[ci], 0);
     if (rc == FHERAM_OK && prepare_write) c->state = true;                            // ram.rs:533
     return rc;
 }
@@ -152,8 +159,10 @@ int write_top(fheram_ctx* c, const fheram_addr* addr) {
     }
     c->memo_top = false;
     if (c->n2 == 2) {
-        coordinate_prepare_inv(c, addr, 1, c->d_ggsw_tmp, c->d_prep);                 // ram.rs:260-271
-        ep_chain(c, tree, ref(c->d_part, G, 0), tmp, c->d_prep, (int)c->base2d[1].size(), 1, ws);   // ram.rs:610: the un-rotated ct_lo, in d_part
+        if (c->inv_id[1] == addr->id) wait_inverse(c, c->stream, 1);                   // started by read_prepare_write
+        else coordinate_prepare_inv(c, addr, 1, c->d_ggsw_tmp, prep_inv_of(c, 1));    // ram.rs:260-271
+        c->inv_id[1] = 0;
+        ep_chain(c, tree, ref(c->d_part, G, 0), tmp, prep_inv_of(c, 1), (int)c->base2d[1].size(), 1, ws);   // ram.rs:610: the un-rotated ct_lo, in d_part
         // tree[0] <- ct_lo * X^-rows (ram.rs:629, `rows` rotations by X^-1): nothing in this write reads it again, so
         // the rotation is enqueued behind the rows' work (write_rows) instead of in front of it
         c->tree_rotate_pending = true;
@@ -182,7 +191,9 @@ void write_side_begin(fheram_ctx* c, const fheram_addr* addr) {
         }
         c->memo_alone = 0;
     }
-    coordinate_prepare_inv(c, addr, 0, c->d_ggsw_tmp2, c->d_prep2);
+    if (c->inv_id[0] == addr->id) wait_inverse(c, c->stream2, 0);   // started by read_prepare_write (on this very stream)
+    else coordinate_prepare_inv(c, addr, 0, c->d_ggsw_tmp2, prep_inv_of(c, 0));
+    c->inv_id[0] = 0;
     hipEventRecord(c->ev_join, c->stream2);
     c->cur = c->stream;
     c->side_begun = true;
@@ -213,7 +224,7 @@ int write_rows(fheram_ctx* c, const fheram_addr* addr) {
         ProfScope ps(c, "elementwise", (uint64_t)R * ws);
         hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws, EW_SLICES), dim3(256), 0, c->cur, data, trhi, B, data);   // ram.rs:617,625-626
     }
-    ep_chain(c, data, data, A, c->d_prep2, (int)c->base2d[0].size(), R, ws);                   // ram.rs:644-646
+    ep_chain(c, data, data, A, prep_inv_of(c, 0), (int)c->base2d[0].size(), R, ws);                   // ram.rs:644-646
     c->state = false;                                                                          // ram.rs:648
     c->side_begun = false;
     return FHERAM_OK;

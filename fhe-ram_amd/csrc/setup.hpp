@@ -353,6 +353,7 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipGetLastError());
     c->keys_loaded = true;
+    c->inv_id[0] = c->inv_id[1] = 0;
     return FHERAM_OK;
 }
 
