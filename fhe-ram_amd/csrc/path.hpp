@@ -31,7 +31,7 @@ int run_op(fheram_ctx* c, const fheram_addr* addr, int which, F&& enqueue) {
         c->memo_top = c->memo != 0;
         c->d_last_res = c->memo_top ? c->d_trtop : c->d_res;
         c->memo_alone = (c->memo && c->n2 == 2 && L0 > 0) ? L0 : 0;
-        if (c->pre_inv) for (int ci = 0; ci < c->n2; ci++) c->inv_id[ci] = addr->id;
+        if (c->pre_inv && (long)c->rows * c->ws <= c->cus) for (int ci = 0; ci < c->n2; ci++) c->inv_id[ci] = addr->id;
     } else { c->memo_top = false; c->memo_alone = 0; c->side_begun = false; c->tree_rotate_pending = false; c->inv_id[0] = c->inv_id[1] = 0; }
     c->prep1_ready = false;
     return FHERAM_OK;
@@ -122,7 +122,9 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
     // ram.rs:571-572): it lands in d_trtop, which no read overwrites, and stays there for the write
     // the write's inverse digits, next to the trace chain below (one launch on half of the XCDs; the side stream has the
     // lowest priority, so that launch is placed first)
-    if (prepare_write && c->pre_inv)
+    // (only while the write's chains are one workgroup round on the chip: with several rounds — 2^21 on one GPU — the
+    // earlier start of the write's main chain interleaves it with the side chain less favourably, write 8.57 -> 8.74 ms)
+    if (prepare_write && c->pre_inv && (long)c->rows * c->ws <= c->cus)
         for (int ci = c->n2 - 1; ci >= 0; ci--) precompute_inverse(c, addr, ci, ci == c->n2 - 1);   // coordinate 1 first: the write's head needs it first
     c->memo_top = prepare_write && c->memo;
     c->d_last_res = c->memo_top ? c->d_trtop : c->d_res;
@@ -134,7 +136,7 @@ int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
     int rc = read_local(c, addr, prepare_write, &packed, false);
     if (rc != FHERAM_OK) return rc;
     rc = read_top(c, addr, prepare_write, nullptr, packed);
-    if (prepare_write && c->pre_inv && capturing(c))                                  // a capture ends with every fork joined
+    if (prepare_write && c->inv_id[0] == addr->id && capturing(c))                    // a capture ends with every fork joined
         for (int ci = 0; ci < c->n2; ci++) hipStreamWaitEvent(c->stream, c->ev_inv[ci], 0);
     if (rc == FHERAM_OK && prepare_write) c->state = true;                            // ram.rs:533
     return rc;
