@@ -107,7 +107,6 @@ struct fheram_ctx {
     int cus = 256;
     double* d_prep = nullptr;      // [n_digits] prepared GGSW: coordinate ci at its first digit (write: inverse digits at 0)
     bool prep1_ready = false;      // coordinate 1 was prepared together with coordinate 0 (unsharded reads)
-    double* d_prep2 = nullptr;     // second set (inverse coordinate 0, prepared on the side stream)
     int32_t* d_ggsw_tmp = nullptr; // [max digits per coordinate] std GGSW (inversion result)
     int32_t* d_ggsw_tmp2 = nullptr;
     int max_digits = 0;

@@ -158,7 +158,6 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_scrB, nrow * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_scrC, nrow * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_scrD, nrow * G * sizeof(int32_t)));
-    CCHK(hipMalloc(&c->d_prep2, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(double)));
     CCHK(hipMalloc(&c->d_ggsw_tmp2, (size_t)c->max_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_tmp2, (size_t)c->ws * G * sizeof(int32_t)));
     CCHK(hipMalloc(&c->d_part, (size_t)c->ws * G * sizeof(int32_t)));
@@ -201,7 +200,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_prep2, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
     if (c->stream) hipStreamDestroy(c->stream);
