@@ -12,6 +12,11 @@ keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(synth((12, 3 * 4
 addr = pkg.Address(p, list(synth((p.base2d().as_1d().size(), p.ggsw_len()))))
 ram.load_encrypted(synth((4, ram.local_rows(), p.glwe_len())))
 ram.stage_words(synth((4, p.glwe_len())))
+if len(sys.argv) > 1:      # N ms of unrelated GPU work first (the external-product microbenchmark): is the ramp the device's clocks?
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < float(sys.argv[1]):
+        ram.bench_external_product(256, 8)
+    print("busy for %.0f ms before the first step" % ((time.perf_counter() - t0) * 1e3), flush=True)
 for i in range(12):
     ts = []
     t0 = time.perf_counter()
