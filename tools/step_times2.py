@@ -23,6 +23,7 @@ def steps(tag, w, n):
         t0 = time.perf_counter()
         for fn in (lambda: ram.read(addr, keys, download=False), lambda: ram.read_prepare_write(addr, keys, download=False), lambda: ram.write(None, addr, keys)):
             fn()
+        ram.sync()
         out.append((time.perf_counter() - t0) * 1e3)
     print(tag, " ".join("%.2f" % t for t in out), flush=True)
 A = world()
