@@ -103,7 +103,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         const char* mm = getenv("FHERAM_MEMO");
         c->memo = (mm && mm[0] == '0') ? 0 : 1;
         const char* pi = getenv("FHERAM_PRE_INV");
-        c->pre_inv = (c->memo && !(pi && pi[0] == '0')) ? 1 : 0;
+        c->pre_inv = (c->memo && !(pi && pi[0] == '0')) ? ((pi && pi[0] == '2') ? 2 : 1) : 0;
         const char* tl = getenv("FHERAM_TAIL");
         c->tail = (tl && tl[0] == '0') ? 0 : 1;
         static std::atomic<int> serial{0};

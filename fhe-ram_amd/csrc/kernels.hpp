@@ -862,6 +862,18 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) 
 //   sync: [group][32] words: arrivals, leavers, XCC mask;  sync[8*32] = abort generation
 // ---------------------------------------------------------------------------------------
 constexpr int TAIL_GROUPS = 8;
+// One wave on the side stream that holds back what is enqueued behind it until the single-launch trace chain of
+// generation `seq` says its workgroups are placed (sync[8*32 + 2]), or GATE_SPIN_MAX polls have passed (~3 ms: only the
+// timing of the work behind it depends on this, never a result).  An event recorded on the main stream for the same
+// purpose delays the launch behind it by 7-13 us; a stream wait-value makes the command processor poll (slower still).
+constexpr int GATE_SPIN_MAX = 1 << 13;
+__global__ __launch_bounds__(64) void k_tail_gate(const unsigned* gate, unsigned seq) {
+    if (threadIdx.x != 0) return;
+    for (int spin = 0; spin < GATE_SPIN_MAX; spin++) {
+        if ((int)(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
 constexpr int TAIL_SPIN_MAX = 1 << 14;   // x one L2 round trip (>= 0.3 us) >= 5 ms
 struct TailArgs {
     GlweRef src, buf[2];             // step i writes buf[i & 1] (buf[0] must not be the source)
@@ -915,6 +927,8 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int G = 2 * SK * SX;
     const int g = ((int)blockIdx.x + TAIL_GROUPS - ta.xoff) % TAIL_GROUPS, m = (int)blockIdx.x / TAIL_GROUPS;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)   // the last block: every block of the launch has been placed (k_tail_gate)
+        __hip_atomic_store(ta.sync + TAIL_GROUPS * 32 + 2, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (g >= ta.n_ct) return;
     const int tid = threadIdx.x;
     double* tw = lds;

@@ -303,8 +303,11 @@ bool capturing(const fheram_ctx* c) { return c->use_graph && !c->profile; }
 // (Starting the side work from a signal word the trace chain's launch writes when its workgroups are placed —
 // hipStreamWaitValue32, no event on the main stream — was measured: the command processor polling that word for the
 // ~600 us until then slows every dispatch of the main stream, read_prepare_write 0.78 -> 0.95 ms at 2^18.)
-void precompute_inverse(fheram_ctx* c, const fheram_addr* addr, int ci, bool fork) {
-    if (fork) {
+// gate_seq != 0: no event; a one-wave gate launch on the side stream waits for the trace chain launch of that generation.
+void precompute_inverse(fheram_ctx* c, const fheram_addr* addr, int ci, bool fork, unsigned gate_seq = 0) {
+    if (fork && gate_seq) {
+        hipLaunchKernelGGL(k_tail_gate, dim3(1), dim3(64), 0, c->stream2, c->d_tail_sync + TAIL_GROUPS * 32 + 2, gate_seq);
+    } else if (fork) {
         hipEventRecord(c->ev_fork, c->stream);
         hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
     }

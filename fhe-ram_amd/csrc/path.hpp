@@ -124,11 +124,18 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
     // lowest priority, so that launch is placed first)
     // (only while the write's chains are one workgroup round on the chip: with several rounds — 2^21 on one GPU — the
     // earlier start of the write's main chain interleaves it with the side chain less favourably, write 8.57 -> 8.74 ms)
-    if (prepare_write && c->pre_inv && (long)c->rows * c->ws <= c->cus)
+    const bool pre = prepare_write && c->pre_inv && (long)c->rows * c->ws <= c->cus;
+    const bool gated = pre && c->pre_inv == 1 && !capturing(c) && use_tail(c, LOGN, 1, ws);   // FHERAM_PRE_INV=2: event fork (A/B switch)
+    if (pre && !gated)
         for (int ci = c->n2 - 1; ci >= 0; ci--) precompute_inverse(c, addr, ci, ci == c->n2 - 1);   // coordinate 1 first: the write's head needs it first
     c->memo_top = prepare_write && c->memo;
     c->d_last_res = c->memo_top ? c->d_trtop : c->d_res;
+    const uint64_t tl0 = c->tail_launches;
     trace_steps(c, last, ref(c->d_last_res, G, 0), tmp, 0, LOGN, 1, ws);              // ram.rs:457 / 540
+    if (gated) {   // behind a gate that opens when the trace chain's launch is placed (no event on the main stream); host order is irrelevant
+        const unsigned seq = c->tail_launches != tl0 ? c->tail_seq : 0;                // 0: no such launch after all -> event fork
+        for (int ci = c->n2 - 1; ci >= 0; ci--) precompute_inverse(c, addr, ci, ci == c->n2 - 1, seq);
+    }
     return FHERAM_OK;
 }
 int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
