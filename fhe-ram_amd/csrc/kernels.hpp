@@ -863,7 +863,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) 
 // ---------------------------------------------------------------------------------------
 constexpr int TAIL_GROUPS = 8;
 // One wave on the side stream that holds back what is enqueued behind it until the single-launch trace chain of
-// generation `seq` says its workgroups are placed (sync[8*32 + 2]), or GATE_SPIN_MAX polls have passed (~3 ms: only the
+// generation `seq` says its workgroups are placed (sync[8*32 + 2]), or GATE_SPIN_MAX polls have passed (a few ms: only the
 // timing of the work behind it depends on this, never a result).  An event recorded on the main stream for the same
 // purpose delays the launch behind it by 7-13 us; a stream wait-value makes the command processor poll (slower still).
 constexpr int GATE_SPIN_MAX = 1 << 13;
