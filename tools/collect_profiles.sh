@@ -15,7 +15,9 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/lds -- $B > $O/lds.json 2> $O/lds.err
 cd $R
 python tools/trace_summary.py $O/stats 40 > $O/kernel_trace_by_grid.txt
-python tools/trace_timeline.py $O/stats 0 100000 | tail -330 > $O/timeline.txt
+(cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python3 $R/bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-boundary --no-kernel-timing > $O/tl.json 2> $O/tl.err)
+python tools/trace_timeline.py $O/tl 0 100000 | tail -420 | head -260 > $O/timeline.txt   # steps of the timed region, no per-launch events
+rm -rf $O/tl
 cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv
 python tools/pmc_hbm.py $O/cfetch $O/cwrite $O/fetch $O/write > $O/pmc_hbm_traffic.json
 python tools/pmc_sq_summary.py pmc_sq=$O/sq pmc_lds=$O/lds > $O/pmc_sq_summary.txt
