@@ -142,6 +142,9 @@ struct fheram_ctx {
     double* d_prep_inv = nullptr;  // [n_digits] prepared GGSW
     int32_t* d_ggsw_inv = nullptr; // [n_digits] std GGSW: the inversion result on its way there (own scratch: runs beside anything)
     hipEvent_t ev_inv[2] = {nullptr, nullptr};
+    bool inv_pending[2] = {false, false};   // a precompute of coordinate ci has been enqueued on the side stream and no write has consumed / overwritten it
+    hipEvent_t ev_wdone = nullptr;          // recorded at the end of every write (main stream): the next precompute waits for it
+    bool wdone_pending = false;
     bool memo_top = false;
     int memo_alone = 0;
     int32_t* d_trtop = nullptr;    // [ws]
@@ -165,6 +168,7 @@ struct fheram_addr {
     int device;
     uint64_t id = next_addr_id();   // never reused (a freed address may be followed by another one at the same pointer)
     hipGraphExec_t graph[3] = {nullptr, nullptr, nullptr};   // captured launch sequences: read, read_prepare_write, write
+    unsigned graph_sig[3] = {0, 0, 0};                       // context state the capture depended on (run_op)
 };
 
 struct fheram_fheuint {

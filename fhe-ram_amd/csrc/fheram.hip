@@ -113,6 +113,9 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* gr = getenv("FHERAM_GRAPH");
         c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
+        // a captured launch sequence must be a pure function of (context, address, op): under replay the write always
+        // computes its own inverse digits (whether a precompute matched is state the capture would freeze)
+        if (c->use_graph) c->pre_inv = 0;
         const char* e = getenv("FHERAM_NCO");
         c->nco = (e && e[0] == '2') ? 2 : ((e && e[0] == '1') ? 1 : 0);
         hipDeviceProp_t prop;
@@ -175,6 +178,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_prep_inv, (size_t)c->n_digits * fheram_ctx::GGSW * sizeof(double)));
     CCHK(hipMalloc(&c->d_ggsw_inv, (size_t)c->n_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     for (int i = 0; i < 2; i++) CCHK(hipEventCreateWithFlags(&c->ev_inv[i], hipEventDisableTiming));
+    CCHK(hipEventCreateWithFlags(&c->ev_wdone, hipEventDisableTiming));
     CCHK(hipMalloc(&c->d_tail_sync, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     CCHK(hipMemset(c->d_tail_sync, 0, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     CCHK(hipHostMalloc((void**)&c->h_tail_fb, 64, hipHostMallocDefault));
@@ -193,6 +197,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     for (int i = 0; i < 2; i++) if (c->ev_inv[i]) hipEventDestroy(c->ev_inv[i]);
+    if (c->ev_wdone) hipEventDestroy(c->ev_wdone);
     if (c->ev_xout) hipEventDestroy(c->ev_xout);
     if (c->ev_xin) hipEventDestroy(c->ev_xin);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -222,6 +227,8 @@ int fheram_keys_load(fheram_ctx* c, const int64_t* gal_els, int n_gal, const int
     if (n_gal != LOGN) return fail(c, FHERAM_ERR_KEYS, "expected log2(N) trace keys (keys.rs:39)");
     if (atk_ggsw_inv_p != -1) return fail(c, FHERAM_ERR_KEYS, "auto_key.p() != -1 (coordinate_prepared.rs:134)");
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));   // a precompute started by read_prepare_write may still be reading the old keys
     // keys may come in any order (the reference keeps them in a HashMap, keys.rs:28): sort by Galois element
     int order[LOGN];
     for (int i = 0; i < LOGN; i++) {
@@ -247,6 +254,8 @@ int fheram_keys_load(fheram_ctx* c, const int64_t* gal_els, int n_gal, const int
     HIPCHK(c, hipGetLastError());
     c->keys_loaded = true;
     c->inv_id[0] = c->inv_id[1] = 0;   // inverse digits prepared with the previous keys are void
+    c->inv_pending[0] = c->inv_pending[1] = false;
+    c->memo_top = false; c->memo_alone = 0;   // ... and so are the traces read_prepare_write kept for the write (ram.rs:572,616 use the keys of the write)
     return FHERAM_OK;
 }
 

@@ -160,6 +160,7 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
 // hand-offs (k_trace_tail), followed by the fused chain launch that only runs if that one gave up.
 bool use_tail(const fheram_ctx* c, int n, int gx, int gy) {
     return c->tail && c->limb_split && c->fine_split && n >= 2 && n <= CHAIN_MAX && (long)gx * gy <= TAIL_GROUPS &&
+           c->cur == c->stream &&            // every launch of a context shares d_tail_sync: main stream only
            c->cus >= TAIL_GROUPS * 32 &&     // the whole chip (8 XCDs x 32 CUs): a partition could not hold the groups side by side
            !(c->use_graph && !c->profile);   // a captured launch would replay its generation number
 }
@@ -305,6 +306,10 @@ bool capturing(const fheram_ctx* c) { return c->use_graph && !c->profile; }
 // ~600 us until then slows every dispatch of the main stream, read_prepare_write 0.78 -> 0.95 ms at 2^18.)
 // gate_seq != 0: no event; a one-wave gate launch on the side stream waits for the trace chain launch of that generation.
 void precompute_inverse(fheram_ctx* c, const fheram_addr* addr, int ci, bool fork, unsigned gate_seq = 0) {
+    if (fork && c->wdone_pending) {   // behind the last write's readers of d_prep_inv (recorded at the end of that write: free)
+        hipStreamWaitEvent(c->stream2, c->ev_wdone, 0);
+        c->wdone_pending = false;
+    }
     if (fork && gate_seq) {
         hipLaunchKernelGGL(k_tail_gate, dim3(1), dim3(64), 0, c->stream2, c->d_tail_sync + TAIL_GROUPS * 32 + 2, gate_seq);
     } else if (fork) {
@@ -317,6 +322,7 @@ void precompute_inverse(fheram_ctx* c, const fheram_addr* addr, int ci, bool for
     hipEventRecord(c->ev_inv[ci], c->stream2);
     c->cur = keep;
     c->inv_id[ci] = addr->id;
+    c->inv_pending[ci] = true;
 }
 void wait_inverse(fheram_ctx* c, hipStream_t s, int ci) { if (!capturing(c)) hipStreamWaitEvent(s, c->ev_inv[ci], 0); }
 

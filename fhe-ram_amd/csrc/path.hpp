@@ -4,12 +4,18 @@
 
 namespace {
 
-// The launch sequence of an op is a pure function of (context, address, op): with FHERAM_GRAPH=1 it is
-// captured once per address into a hipGraph and replayed, instead of being re-enqueued kernel by kernel.
+// The launch sequence of an op is a function of (context, address, op) and of a few bits of the context's state (what a
+// write may resume from): with FHERAM_GRAPH=1 it is captured once per address and state signature into a hipGraph and
+// replayed, instead of being re-enqueued kernel by kernel.
 template <typename F>
 int run_op(fheram_ctx* c, const fheram_addr* addr, int which, F&& enqueue) {
     if (!c->use_graph || c->profile) return enqueue();
     fheram_addr* a = const_cast<fheram_addr*>(addr);
+    // what the enqueue function reads of the context's mutable state (a write resumes from what read_prepare_write kept —
+    // or not, after a key load or with another address): a capture taken under another signature is not replayed
+    const unsigned sig = 1u | (c->memo_top ? 2u : 0u) | ((unsigned)c->memo_alone << 2) | (c->side_begun ? 64u : 0u) |
+                         (c->inv_id[0] == addr->id ? 128u : 0u) | (c->inv_id[1] == addr->id ? 256u : 0u);
+    if (a->graph[which] && a->graph_sig[which] != sig) { hipGraphExecDestroy(a->graph[which]); a->graph[which] = nullptr; }
     if (!a->graph[which]) {
         hipGraph_t g = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -22,6 +28,7 @@ int run_op(fheram_ctx* c, const fheram_addr* addr, int which, F&& enqueue) {
         const hipError_t e2 = hipGraphInstantiate(&a->graph[which], g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (e2 != hipSuccess) { a->graph[which] = nullptr; return fail(c, FHERAM_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+        a->graph_sig[which] = sig;
     }
     HIPCHK(c, hipGraphLaunch(a->graph[which], c->stream));
     // the host-side bookkeeping the enqueue functions do (a replay does not run them)
@@ -169,7 +176,13 @@ int write_top(fheram_ctx* c, const fheram_addr* addr) {
     c->memo_top = false;
     if (c->n2 == 2) {
         if (c->inv_id[1] == addr->id) wait_inverse(c, c->stream, 1);                   // started by read_prepare_write
-        else coordinate_prepare_inv(c, addr, 1, c->d_ggsw_tmp, prep_inv_of(c, 1));    // ram.rs:260-271
+        else {
+            // another address (or new keys): a precompute that read_prepare_write started for ITS address may still be
+            // writing prep_inv_of(c, 1) on the side stream — the main stream must not overtake it
+            if (c->inv_pending[1]) wait_inverse(c, c->stream, 1);
+            coordinate_prepare_inv(c, addr, 1, c->d_ggsw_tmp, prep_inv_of(c, 1));     // ram.rs:260-271
+        }
+        c->inv_pending[1] = false;
         c->inv_id[1] = 0;
         ep_chain(c, tree, ref(c->d_part, G, 0), tmp, prep_inv_of(c, 1), (int)c->base2d[1].size(), 1, ws);   // ram.rs:610: the un-rotated ct_lo, in d_part
         // tree[0] <- ct_lo * X^-rows (ram.rs:629, `rows` rotations by X^-1): nothing in this write reads it again, so
@@ -201,8 +214,9 @@ void write_side_begin(fheram_ctx* c, const fheram_addr* addr) {
         c->memo_alone = 0;
     }
     if (c->inv_id[0] == addr->id) wait_inverse(c, c->stream2, 0);   // started by read_prepare_write (on this very stream)
-    else coordinate_prepare_inv(c, addr, 0, c->d_ggsw_tmp2, prep_inv_of(c, 0));
+    else coordinate_prepare_inv(c, addr, 0, c->d_ggsw_tmp2, prep_inv_of(c, 0));   // (a precompute for another address sits on this very stream: ordered)
     c->inv_id[0] = 0;
+    c->inv_pending[0] = false;
     hipEventRecord(c->ev_join, c->stream2);
     c->cur = c->stream;
     c->side_begun = true;
@@ -234,6 +248,9 @@ int write_rows(fheram_ctx* c, const fheram_addr* addr) {
         hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws, EW_SLICES), dim3(256), 0, c->cur, data, trhi, B, data);   // ram.rs:617,625-626
     }
     ep_chain(c, data, data, A, prep_inv_of(c, 0), (int)c->base2d[0].size(), R, ws);                   // ram.rs:644-646
+    // the next read_prepare_write's side work overwrites d_prep_inv: it is ordered behind this write by an event (the gate
+    // launch in front of that work is time-bounded, so it cannot be the only ordering)
+    if (!capturing(c)) { hipEventRecord(c->ev_wdone, c->stream); c->wdone_pending = true; }
     c->state = false;                                                                          // ram.rs:648
     c->side_begun = false;
     return FHERAM_OK;

@@ -297,6 +297,8 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     if (rc == FHERAM_OK) rc = check_setup_args(c, sk, fheram_ctx::S_INV, (int)c->p.k_evk_ggsw_inv);
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));   // a precompute started by read_prepare_write may still be reading the old keys
     c->cur = c->stream;
     int32_t *d_stage = nullptr, *d_small = nullptr;
     double* d_hat = nullptr;
@@ -354,6 +356,8 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     HIPCHK(c, hipGetLastError());
     c->keys_loaded = true;
     c->inv_id[0] = c->inv_id[1] = 0;
+    c->inv_pending[0] = c->inv_pending[1] = false;
+    c->memo_top = false; c->memo_alone = 0;
     return FHERAM_OK;
 }
 
