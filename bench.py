@@ -41,6 +41,8 @@ ATK_I64 = 3 * 4 * 2 * N * 8         # 786 432 B
 EVK5_I64 = 4 * 5 * 2 * N * 8        # 1 310 720 B
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TINSTR = 39.3        # 78.6 TFLOP/s vector FP64 = 39.3 T FMA-class instr/s
+FP64_PER_KS = 11 * 24576 * 8 + 24 * 4096 * 7    # trace / packer key-switch: 11 transforms x 24576 butterflies x 8 + 24 x 4096 MACs x 7
+FP64_PER_EP = 14 * 24576 * 8 + 48 * 4096 * 7    # external product: 14 transforms, 48 polynomial MACs
 
 
 def synth(rng, shape):
@@ -124,15 +126,38 @@ def host_cpu():
 
 
 def host_cores():
-    """threads of the all-core CPU baseline: the cores this process may use, capped at the GPU box's CPU share per GPU
-    (16; FHERAM_CPU_THREADS overrides)"""
+    """threads of the all-core CPU baseline: every core this process may use (scheduler affinity, then the cgroup's CPU
+    quota if it is smaller); FHERAM_CPU_THREADS overrides"""
     if os.environ.get("FHERAM_CPU_THREADS"):
         return int(os.environ["FHERAM_CPU_THREADS"])
     try:
         n = len(os.sched_getaffinity(0))
     except Exception:
         n = os.cpu_count() or 1
-    return min(n, 16)
+    try:   # cgroup v2 quota ("max 100000" = none)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without torch.distributed.run around it: run that launcher as a child process
+    (one rank per GPU over RCCL), pass its output through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    if r.returncode != 0:
+        print(f"bench.py: the {args.gpus}-rank run failed (exit code {r.returncode}); no 1-GPU fallback", file=sys.stderr)
+    return r.returncode
 
 
 def bench_ep(pkg, args):
@@ -146,7 +171,7 @@ def bench_ep(pkg, args):
     big = [ram.bench_external_product(8 * cus, 8) / 8 for _ in range(args.steps)]
     lat_ms, thr_ms, big_ms = float(np.median(lat)), float(np.median(thr)), float(np.median(big))
     ep_bytes = 2 * GLWE_I64 + GGSW_I64            # a + G + res, int64-limb layout
-    fp64_per_ep = 14 * 24576 * 8 + 48 * 4096 * 7
+    fp64_per_ep = FP64_PER_EP
     out = {"metric": "GLWE x GGSW external products per second at N=4096 (BASELINE.json configs[1])",
            "value": cus / (thr_ms * 1e-3), "unit": "external products/s (batch = #CUs per launch)",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": thr_ms, "higher_is_better": True,
@@ -155,13 +180,16 @@ def bench_ep(pkg, args):
            "latency_us_single_product": lat_ms * 1e3,
            "batch_launch_us": {str(cus): thr_ms * 1e3, str(8 * cus): big_ms * 1e3},
            "amortised_us_per_product": {str(cus): thr_ms * 1e3 / cus, str(8 * cus): big_ms * 1e3 / (8 * cus)},
-           "roofline": {"kernel": "k_ext_product<3,4,2,0> (one workgroup per product)", "bound": "hbm",
-                        "achieved": (cus * 2 * GLWE_I64 + GGSW_I64) / thr_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": (cus * 2 * GLWE_I64 + GGSW_I64) / thr_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
-                        "algorithmic_bytes_single_product": ep_bytes},
-           "roofline_valu": {"bound": "valu_fp64", "achieved": cus * fp64_per_ep / (thr_ms * 1e-3) / 1e12,
-                             "peak": FP64_VALU_PEAK_TINSTR, "unit": "T FP64 instr/s",
-                             "frac": cus * fp64_per_ep / (thr_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR},
+           "roofline": {"kernel": "k_ext_product<3,4,2,0> (one workgroup per product)", "bound": "valu_fp64",
+                        "achieved": 2 * cus * fp64_per_ep / (thr_ms * 1e-3) / 1e12, "peak": 2 * FP64_VALU_PEAK_TINSTR, "unit": "TFLOP/s",
+                        "frac": cus * fp64_per_ep / (thr_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR, "traffic": None,
+                        "note": "every FP64 VALU instruction priced as one FMA slot (2 FLOP)"},
+           "roofline_hbm": {"bound": "hbm", "achieved": (cus * GLWE_I64 + GGSW_I64) / thr_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": (cus * GLWE_I64 + GGSW_I64) / thr_ms / 1e6 / HBM_PEAK_GBS,
+                            "what": "device layout: int32 limbs in and out (= GLWE_I64 bytes per product), f64 GGSW once",
+                            "abi_layout_int64": {"achieved": (cus * 2 * GLWE_I64 + GGSW_I64) / thr_ms / 1e6,
+                                                 "frac": (cus * 2 * GLWE_I64 + GGSW_I64) / thr_ms / 1e6 / HBM_PEAK_GBS,
+                                                 "algorithmic_bytes_single_product": ep_bytes}},
            "device": ram.device_info()}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -204,11 +232,16 @@ def main():
     ap.add_argument("--no-boundary", action="store_true", help="skip the pass that includes the host hand-over")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # Started without a launcher: start the N ranks ourselves, as fresh child processes, BEFORE this process has
+        # touched the GPU (nothing above imports torch or loads the HIP library), relay rank 0's JSON line and exit with
+        # the launcher's code.  Never a silent 1-GPU run.
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure another job than the one asked for")
     mode = args.mode if args.mode != "auto" else ("sharded" if world > 1 else "single")
     # the sharded path can be rehearsed with ONE rank (RCCL + device buffers + event hand-over) under torch.distributed.run
     use_dist = world > 1 or (mode == "sharded" and "RANK" in os.environ)
@@ -387,6 +420,9 @@ def main():
                                       "gave up (CUs not available side by side) and were redone by the fused launch behind them"),
         "device": ram.device_info(),
     }
+    if tail["fallbacks"] > 0:
+        out["trace_tail_degraded"] = True     # silent degradation made visible: some single-launch chains were redone by their fallback
+        print(f"bench.py: WARNING: {tail['fallbacks']} of {tail['launches']} single-launch trace chains fell back", file=sys.stderr)
     if boundary is not None:
         out["read_ms_incl_boundary"], out["rpw_ms_incl_boundary"], out["write_ms_incl_boundary"] = [float(x) for x in boundary]
         out["boundary_note"] = ("host wall clock per call with the ABI's int64 host buffers: result download (ws GLWEs) on the two "
@@ -406,32 +442,58 @@ def main():
             blocks = kf["blocks"] / kf["launches"]
             bytes_abi = blocks * 2 * GLWE_I64 + ATK_I64              # in + out GLWE (int64 limbs) + key once
             bytes_dev = blocks * 2 * (GLWE_I64 // 2) + ATK_I64       # what the device layout must move: int32 limbs, f64 key
-            achieved = bytes_abi / avg_ms / 1e6
-            fp64_per_block = 11 * 24576 * 8 + 24 * 4096 * 7         # 11 transforms x 24576 butterflies x 8 + 24 x 4096 MACs x 7
+            ach = kf["blocks"] * FP64_PER_KS / (kf["ms"] * 1e-3) / 1e12          # T FP64 VALU instructions / s
+            chain = classes["keyswitch_chain_launch"]
+            # PRIMARY roofline = the roof that binds this kernel: the FP64 vector ALU.  Every FP64 VALU instruction
+            # (mul / add / fma / rndne: all issue at the FMA rate) is priced as one FMA slot = 2 FLOP, so that achieved
+            # and peak are in the guide's TFLOP/s; frac = instruction rate / 39.3 T instr/s.
             out["roofline"] = {"kernel": "fused trace step (ks_run<KS_TRACE,3,4,3,NCO=2> inside k_keyswitch_chain<3,4,3> / k_keyswitch<1,3,4,3,2,0>), one workgroup per ciphertext",
-                               "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
-                               "traffic_source": PMC_PROFILE + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                                 "FETCH_SIZE scaled by the factor calibrated on a known-bytes 4-B/lane int32 stream, tools/fetch_calib.hip)",
+                               "bound": "valu_fp64", "achieved": 2 * ach, "peak": 2 * FP64_VALU_PEAK_TINSTR, "unit": "TFLOP/s",
+                               "frac": ach / FP64_VALU_PEAK_TINSTR,
+                               "achieved_T_fp64_instr_s": ach, "peak_T_fp64_instr_s": FP64_VALU_PEAK_TINSTR,
+                               "fp64_instr_per_keyswitch": FP64_PER_KS,
+                               "traffic": pmc_traffic_per_launch(),
+                               "traffic_source": PMC_PROFILE + " (HBM bytes per step of this kernel: separate rocprofv3 --pmc FETCH_SIZE / "
+                                                 "WRITE_SIZE passes of this command, FETCH_SIZE scaled by the factor calibrated on a "
+                                                 "known-bytes 4-B/lane int32 stream, tools/fetch_calib.hip)",
                                "avg_launch_ms": avg_ms, "avg_blocks_per_launch": blocks, "launches": kf["launches"],
-                               "chain_launch": ({"kernel": "k_keyswitch_chain<3,4,3>", "launches": classes["keyswitch_chain_launch"]["launches"],
-                                                 "avg_launch_ms": classes["keyswitch_chain_launch"]["ms"] / classes["keyswitch_chain_launch"]["launches"],
-                                                 "avg_steps_per_launch": classes["keyswitch_chain_launch"]["blocks"] / classes["keyswitch_chain_launch"]["launches"] / blocks}
-                                                if classes["keyswitch_chain_launch"]["launches"] else None),
-                               "algorithmic_bytes_per_launch": bytes_abi,
-                               "device_layout_bytes_per_launch": bytes_dev, "achieved_device_layout": bytes_dev / avg_ms / 1e6,
-                               "frac_device_layout": bytes_dev / avg_ms / 1e6 / HBM_PEAK_GBS,
-                               "note": "not HBM-bound: the binding roof is the FP64 vector ALU (roofline_valu)"}
-            ach = kf["blocks"] * fp64_per_block / (kf["ms"] * 1e-3) / 1e12
-            out["roofline_valu"] = {"kernel": "same launches", "bound": "valu_fp64", "achieved": ach, "peak": FP64_VALU_PEAK_TINSTR,
-                                    "unit": "T FP64 instr/s", "frac": ach / FP64_VALU_PEAK_TINSTR, "measured_issue_peak": 36.0,
-                                    "measured_issue_peak_source": "profiles/r01_valu_rate.txt (tools/valu_rate.hip: mulmod chains sustain 1.8 ns per "
-                                                                  "wave-instruction per SIMD at the 2.15 GHz clock of FP64 load)"}
+                               "launch_unit": "one trace step over the batch (a chain launch runs 6 or 12 of them: HIP-event time of the launch / its steps)",
+                               "chain_launch": ({"kernel": "k_keyswitch_chain<3,4,3>", "launches": chain["launches"],
+                                                 "avg_launch_ms": chain["ms"] / chain["launches"],
+                                                 "avg_steps_per_launch": chain["blocks"] / chain["launches"] / blocks}
+                                                if chain["launches"] else None),
+                               "measured_issue_peak_T_instr_s": 36.0,
+                               "measured_issue_peak_source": "profiles/r01_valu_rate.txt (tools/valu_rate.hip: mulmod chains sustain 1.8 ns per "
+                                                             "wave-instruction per SIMD at the 2.15 GHz clock of FP64 load)"}
             ks = classes["keyswitch"]
             if ks["launches"]:
-                cls = ks["blocks"] * fp64_per_block / (ks["ms"] * 1e-3) / 1e12
-                out["roofline_valu"]["whole_class"] = {"achieved": cls, "frac": cls / FP64_VALU_PEAK_TINSTR,
-                                                       "avg_launch_ms": ks["ms"] / ks["launches"], "avg_blocks_per_launch": ks["blocks"] / ks["launches"]}
+                cls = ks["blocks"] * FP64_PER_KS / (ks["ms"] * 1e-3) / 1e12
+                out["roofline"]["whole_class"] = {"achieved_T_fp64_instr_s": cls, "frac": cls / FP64_VALU_PEAK_TINSTR,
+                                                  "avg_launch_ms": ks["ms"] / ks["launches"], "avg_blocks_per_launch": ks["blocks"] / ks["launches"]}
+            # SECONDARY: the same launches against HBM.  frac is on the bytes the DEVICE layout must move (int32 limbs, f64
+            # key); the int64-limb ABI layout of SURVEY.md 8(d) is reported beside it, labelled.
+            out["roofline_hbm"] = {"kernel": "same launches", "bound": "hbm", "achieved": bytes_dev / avg_ms / 1e6, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": bytes_dev / avg_ms / 1e6 / HBM_PEAK_GBS,
+                                   "device_layout_bytes_per_launch": bytes_dev,
+                                   "abi_layout_int64": {"algorithmic_bytes_per_launch": bytes_abi, "achieved": bytes_abi / avg_ms / 1e6,
+                                                        "frac": bytes_abi / avg_ms / 1e6 / HBM_PEAK_GBS},
+                                   "traffic": pmc_traffic_per_launch(),
+                                   "note": "not the binding roof: everything a 2^18 op touches sits in the 256 MiB Infinity Cache"}
+        # whole step (read + read_prepare_write + write) against both roofs: the op-level view of SURVEY.md 8(d)
+        ep_ref = 2 * cnt["ep_read"] + cnt["ep_write"]
+        ks_ref = 2 * cnt["ks_read"] + cnt["ks_write"]
+        L0 = max(0, 12 - max(0, (cnt["rows"] - 1).bit_length())) if cnt["rows"] > 1 else 0
+        ks_exec = ks_ref - (ws * 12 + ws * cnt["rows"] * L0)     # the write resumes from what read_prepare_write kept (csrc/path.hpp)
+        fp_step = ep_ref * FP64_PER_EP + ks_exec * FP64_PER_KS
+        out["roofline_whole_op"] = {"what": "one step = read + read_prepare_write + write, device-resident, against the same two roofs",
+                                    "hbm": {"algorithmic_bytes_per_step": a_read + a_rpw + a_write,
+                                            "achieved_GBs": (a_read + a_rpw + a_write) / ms_per_step / 1e6,
+                                            "frac": (a_read + a_rpw + a_write) / ms_per_step / 1e6 / HBM_PEAK_GBS},
+                                    "valu_fp64": {"external_products": ep_ref, "key_switches_reference": ks_ref, "key_switches_executed": ks_exec,
+                                                  "fp64_instr_per_step": fp_step,
+                                                  "achieved_T_fp64_instr_s": fp_step / (ms_per_step * 1e-3) / 1e12,
+                                                  "frac": fp_step / (ms_per_step * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR,
+                                                  "note": "GGSW prepares and inversions (< 2 % of the work) not counted"}}
         out["kernel_classes"] = classes
         out["kernel_timing_pass"] = {"what": "separate pass of the same K steps with per-launch HIP events on the launch stream "
                                              "(not part of the timed region: the events add this much to a step)",

@@ -111,6 +111,9 @@ _SYMBOLS = [
     ("fheram_profile_reset", C.c_int, [C.c_void_p]),
     ("fheram_bench_external_product", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("fheram_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    ("fheram_selftest_modarith", C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 6),
+    ("fheram_selftest_ntt", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("fheram_selftest_constants", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 ]
 
 
@@ -749,6 +752,21 @@ class Ram:
         ms = C.c_float()
         self._chk(library().fheram_bench_external_product(self._h, batch, iters, C.byref(ms)))
         return float(ms.value)
+
+    # -- self-tests of the FP64 modular arithmetic (tests/test_gpu_modarith.py)
+    def selftest_modarith(self, a, b, acc):
+        a, b, acc = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, b, acc))
+        outs = [np.zeros_like(a) for _ in range(3)]
+        dp = lambda v: v.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+        self._chk(library().fheram_selftest_modarith(self._h, a.size, dp(a), dp(b), dp(acc), *[dp(o) for o in outs]))
+        return outs
+
+    def selftest_ntt(self, direction: int, polys):
+        x = np.ascontiguousarray(polys, dtype=np.float64).reshape(-1, self.params.n())
+        out = np.zeros_like(x)
+        dp = lambda v: v.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+        self._chk(library().fheram_selftest_ntt(self._h, direction, x.shape[0], dp(x), dp(out)))
+        return out
 
     def device_info(self):
         buf = C.create_string_buffer(256)

@@ -684,3 +684,4 @@ int fheram_device_info(const fheram_ctx* c, char* name, size_t name_len, int* cu
 }  // extern "C"
 
 #include "setup.hpp"
+#include "selftest.hpp"

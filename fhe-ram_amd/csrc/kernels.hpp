@@ -754,7 +754,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
             fetch(j);
             double acc[1][E];
             mac(acc[0], -1);
-            ntt_inv<1, false>(acc, tw, data, tid);   // the only inverse transform of this workgroup
+            ntt_inv<1, false, (SX > 3)>(acc, tw, data, tid);   // the only inverse transform of this workgroup
             add_body(acc[0], j);
             double* bgp = ka.big + big_ct() + (long)(co * SK + j) * N;
 #pragma unroll
@@ -778,7 +778,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
                 if (j - KBI >= 0) fetch(j - KBI);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            ntt_inv<KBI, !DB>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
+            ntt_inv<KBI, !DB, (SX > 3)>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);   // <= 3 MAC terms: no initial reduce
             if constexpr (FK_EARLY_FETCH == 0) { if (j - KBI >= 0) fetch(j - KBI); }   // (FK_EARLY_FETCH == 2: timing diagnostic, operands never refetched, results wrong)   // next limb's operands: their latency overlaps the post-step
             STAMP(10 + 4 * (SK - 1 - j) + 24 * c);
 #pragma unroll
@@ -791,7 +791,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
         if constexpr (REM == 1) {
             double acc[1][E];
             mac(acc[0], -1);
-            ntt_inv<1, !DB>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
+            ntt_inv<1, !DB, (SX > 3)>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
             add_body(acc[0], 0);
             emit(acc[0], 0);
         }
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
         for (int k = 0; k < E; k++) acc[0][k] = 0.0;
         mac_regs(acc[0], x[0], kop);
         if (!last) load_ops(kop, ta.key[s + 1] + (long)((r * SK + j) * 2 + co) * N, tid);   // arrives during the rest of the step
-        ntt_inv<1, false>(acc, tw, data, tid);
+        ntt_inv<1, false, false>(acc, tw, data, tid);
         TSTAMP(3);
         {
             double* bgp = bigg + (long)((co * SK + j) * SX + r) * N;
@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_fine(KsArgs ka) {
     for (int k = 0; k < E; k++) acc[0][k] = 0.0;
     mac_regs(acc[0], x[0], g);
     STAMPZ(5);
-    ntt_inv<1, false>(acc, tw, data, tid);
+    ntt_inv<1, false, false>(acc, tw, data, tid);
     STAMPZ(6);
 #pragma unroll
     for (int k = 0; k < E; k++) acc[0][k] += (double)bodyv[k];
@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product_fine(GlweRef a, cons
 #pragma unroll
     for (int k = 0; k < E; k++) acc[0][k] = 0.0;
     mac_regs(acc[0], x[0], g);
-    ntt_inv<1, false>(acc, tw, data, tid);
+    ntt_inv<1, false, false>(acc, tw, data, tid);
     double* bp = big + big_ct() * (2 * SA) + (long)((co * SG + j) * 2 * SA + cin * SA + r) * N;
 #pragma unroll
     for (int k = 0; k < E; k++) bp[tid + T * k] = acc[0][k];
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(T, T / 256) void k_encrypt_sk(int32_t* __restrict__
         for (int k = 0; k < E; k++) { x[0][k] = (double)mi[k]; acc[0][k] = 0.0; }
         ntt_fwd<1>(x, tw, data, tid);
         mac_regs(acc[0], x[0], sh);
-        ntt_inv<1, false>(acc, tw, data, tid);   // follows a forward transform, whose cross-wave reads are fenced
+        ntt_inv<1, false, false>(acc, tw, data, tid);   // follows a forward transform, whose cross-wave reads are fenced
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const double v = (DEC ? (double)bi[k] + acc[0][k] : (double)bi[k] - acc[0][k]) + carry[k];

@@ -298,8 +298,11 @@ __device__ __forceinline__ void inv_pass(double (&x)[E], const TwPass& t) {
 //  * inverse (Gentleman-Sande): a pass of LOGE stages turns inputs bounded by I into
 //    [E*I, 4p, 2p, 2p, p, ...] (slot 0 is the sum of all E inputs, slot 1 a sum of products);
 //    after the LDS exchange all E values of a thread come from the same slot, so I is uniform per
-//    thread.  Reducing slots 0 and 1 after each pass keeps I <= 2p, the next slot 0 below
-//    E*2p = 16p < 32p and every difference that feeds a product below 16p.
+//    thread.  A product d*w with |d| <= 8I, |w| <= p/2 comes back within (0.5 + |d| * 1.5 * 2^-53) p of zero (q is
+//    off by at most 0.5 + 3 * 2^-53 * |d*w|/p), i.e. <= 1.8p for |d| <= 27p; so a pass leaves at most
+//    [8I, 7.2p, 3.6p, 3.6p, 1.8p, ...]; reducing slots 0 and 1 after each pass keeps I <= 3.6p, the next slot 0 below
+//    29p < 32p = 2^53 / p and every product below 8 * 3.6p * p/2 < 2^101.  (Typical values are far smaller: the
+//    bound is the worst case the self-test drives.)
 template <int Q, int B>
 __device__ __forceinline__ void fwd_rec(double (&x)[B][E], const TwPass& t, const double* tw, double* data, int tid) {
 #pragma unroll
@@ -353,12 +356,19 @@ __device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, dou
 // buffer across waves (the far side of exchange 0 of the previous inverse transform in the SAME
 // buffer); callers that alternate between two buffers, or whose previous transform was a forward one
 // (its cross-wave reads are fenced inside exchange_fwd), pass false.
-template <int B, bool FENCE = true>
+// PRE: reduce the inputs first.  Needed when |x| may exceed ~3.4p (the external product accumulates 6 MAC terms of
+// up to ~1.02p each); the key-switch family accumulates at most 4 terms (|x| <= 4.1p is NOT enough for E = 8: 8 * 4.1p
+// > 32p) — so PRE = false is used for at most 3 terms (|x| <= 3.06p: slot 0 of the first pass <= 24.5p < 32p = 2^53,
+// every product |d*w| <= 8 * 3.06p * p/2 < 2^100), checked on the device with worst-case operands by
+// tests/test_gpu_modarith.py.
+template <int B, bool FENCE = true, bool PRE = true>
 __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, double* data, int tid) {
+    if constexpr (PRE) {
 #pragma unroll
-    for (int b = 0; b < B; b++)
+        for (int b = 0; b < B; b++)
 #pragma unroll
-        for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+            for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+    }
     TwPass t;
     inv_twiddles<NPASS - 1>(t, tw, tid);
     if constexpr (FENCE) lds_barrier();   // first LDS write of this transform: earlier cross-wave readers are done

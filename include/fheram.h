@@ -257,6 +257,20 @@ int fheram_bench_external_product(fheram_ctx* ctx, int batch, int iters, float* 
 /* Device properties of the context's GPU (name, CU count) for the bench report. */
 int fheram_device_info(const fheram_ctx* ctx, char* name, size_t name_len, int* compute_units);
 
+/* ---- Self-tests of the arithmetic the kernels are built on (no reference counterpart: the reference delegates its
+ * arithmetic to Poulpy's FFT64 backend, examples/fhe-ram.rs:3-7; SURVEY.md 7.3 asks for edge tests of the FP64
+ * modular arithmetic against exact integers).  Host doubles in, host doubles out; the caller supplies the adversarial
+ * operands and checks against exact integer arithmetic (tests/test_gpu_modarith.py).  Not on the RAM path. */
+/* out_mul[i] = mulmod(a[i], b[i]); out_mac[i] = macmod(acc[i], a[i], b[i]); out_red[i] = reduce(a[i])  (csrc/ntt_dev.hpp) */
+int fheram_selftest_modarith(fheram_ctx* ctx, int n, const double* a, const double* b, const double* acc, double* out_mul,
+                             double* out_mac, double* out_red);
+/* n_poly polynomials of N doubles through the transforms as the fused kernels call them.  dir 0: forward (natural-order
+ * coefficients in; UNREDUCED transform values out, position 8*tid + k = bit-reversed order); dir 1: inverse x N (centred
+ * coefficients out); dir 2: inverse without the initial reduction (inputs below 3.06 p). */
+int fheram_selftest_ntt(fheram_ctx* ctx, int dir, int n_poly, const double* in, double* out);
+/* the NTT modulus and the primitive 2N-th root of unity the twiddle table is built from */
+int fheram_selftest_constants(uint64_t* p, uint64_t* psi);
+
 #ifdef __cplusplus
 }
 #endif

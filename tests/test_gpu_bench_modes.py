@@ -25,7 +25,7 @@ def test_bench_external_product_mode():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = last_json(r.stdout)
     assert out["value"] > 0 and 1.0 < out["latency_us_single_product"] < 200.0
-    assert 0.0 < out["roofline"]["frac"] < 1.0 and 0.0 < out["roofline_valu"]["frac"] < 1.0
+    assert out["roofline"]["bound"] == "valu_fp64" and 0.0 < out["roofline"]["frac"] < 1.0 and 0.0 < out["roofline_hbm"]["frac"] < 1.0
 
 
 def test_bench_sharded_one_rank_rccl_device_buffers():
@@ -53,3 +53,19 @@ def test_bench_sharded_two_ranks_gloo_on_one_gpu():
         out = last_json(r.stdout)
         assert out["mode"] == "sharded" and out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
         assert "MAX_ADDR=2^14" in out["config"]["workload"]
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (how the driver calls it): bench.py starts the two ranks
+    itself as child processes — never a silent 1-GPU run (VERDICT r02 #1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--all-ranks-device0",
+                        "--log-max-addr", "13", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["mode"] == "sharded" and out["value"] > 0
+    # a launcher environment that contradicts --gpus is refused, not silently reinterpreted
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)
