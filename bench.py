@@ -67,14 +67,14 @@ def op_counts(max_addr, ws, base2d):
             "ggsw_inv": sum(d) * 6}
 
 
-def algorithmic_bytes(max_addr, ws, n_digits):
+def algorithmic_bytes(max_addr, ws, n_digits, atk_i64=ATK_I64):
     """SURVEY.md §8(d) formulas (int64-limb ABI layout, every object counted once)."""
     rows = -(-max_addr // N)
     ram = ws * rows * GLWE_I64
     addr = n_digits * GGSW_I64
-    read = ram + addr + 12 * ATK_I64 + ws * GLWE_I64
-    rpw = 2 * ram + addr + 12 * ATK_I64 + ws * GLWE_I64
-    write = 2 * ram + addr + 12 * ATK_I64 + 2 * EVK5_I64 + ws * GLWE_I64
+    read = ram + addr + 12 * atk_i64 + ws * GLWE_I64
+    rpw = 2 * ram + addr + 12 * atk_i64 + ws * GLWE_I64
+    write = 2 * ram + addr + 12 * atk_i64 + 2 * EVK5_I64 + ws * GLWE_I64
     return read, rpw, write
 
 
@@ -90,14 +90,14 @@ def pmc_traffic_per_launch():
     return json.load(open(path)).get("dominant_kernel", {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(max_addr, ws, seed, threads):
+def cpu_baseline(max_addr, ws, seed, threads, crypto=None):
     """Times the oracle (CPU restatement, kind 'port') on the same workload: one read + one
     read_prepare_write + one write.  threads == 1: ONE of the WORDSIZE sub-RAMs (the reference processes them
     one after the other, ram.rs:187-190; scaled by the caller).  threads > 1: the whole RAM with the oracle's
     OpenMP variant (sub-RAMs and the rows of the per-row loops in parallel)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    o = po.Oracle(po.OParams(max_addr=max_addr, word_size=ws)).set_threads(threads)
+    o = po.Oracle(po.OParams(max_addr=max_addr, word_size=ws, **(crypto or {}))).set_threads(threads)
     p = o.p
     rng = np.random.default_rng(seed)
     evk = {"gal_els": np.array([int(po.lib().fo_galois_element(12, i)) for i in range(12)], dtype=np.int64),
@@ -222,6 +222,10 @@ def main():
                     help="log2 of the entries of the ONE RAM sharded over all GPUs, fixed as N grows (strong scaling; "
                          "BASELINE.json configs[4] = 21)")
     ap.add_argument("--word-size", type=int, default=4)
+    ap.add_argument("--params", choices=["source", "readme"], default="source",
+                    help="cryptographic parameter block: 'source' = the constants of src/parameters.rs:11-18 (default, BASELINE.json's "
+                         "'default params'); 'readme' = the block of README.md:17-27 the published 450 / 1200 ms were taken with "
+                         "(K_PT = 9, K_EVK = 85: 5-limb trace keys)")
     ap.add_argument("--mode", choices=["auto", "sharded", "replicas"], default="auto",
                     help="N > 1: 'sharded' (default) = ONE RAM, rows sharded over the GPUs, one RCCL all-gather per read "
                          "and one broadcast per write; 'replicas' = one independent RAM per GPU, no collective")
@@ -269,6 +273,10 @@ def main():
         return
 
     ws = args.word_size
+    crypto = {"k_glwe_pt": 9, "k_evk_trace": 85} if args.params == "readme" else {}
+    s_evk = 5 if args.params == "readme" else 4          # limbs of a trace / packing key
+    atk_i64 = 3 * s_evk * 2 * N * 8
+    fp64_per_ks = (3 + 2 * s_evk) * 24576 * 8 + 3 * 2 * s_evk * 4096 * 7
     sharded = mode == "sharded"
     strong = sharded and args.total_log_max_addr is not None
     if strong:
@@ -278,13 +286,13 @@ def main():
     else:
         max_addr = 1 << args.log_max_addr
     if sharded:
-        ram = pkg.Ram(pkg.Parameters(max_addr=max_addr, word_size=ws), device=local_rank, shard=rank, n_shards=world)
+        ram = pkg.Ram(pkg.Parameters(max_addr=max_addr, word_size=ws, **crypto), device=local_rank, shard=rank, n_shards=world)
     else:
-        ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr, device=local_rank)
+        ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr, device=local_rank, **crypto)
     p = ram.params
     rng = np.random.default_rng(1234 + (0 if sharded else rank))     # sharded: every rank derives the same keys and address
     n_digits = p.base2d().as_1d().size()
-    keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(synth(rng, (12, 3 * 4 * 2 * N))),
+    keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(synth(rng, (12, 3 * s_evk * 2 * N))),
                                       synth(rng, 4 * 5 * 2 * N), synth(rng, 4 * 5 * 2 * N))
     addr = pkg.Address(p, list(synth(rng, (n_digits, p.ggsw_len()))))
     rng = np.random.default_rng(4321 + rank)
@@ -382,7 +390,7 @@ def main():
     # weak scaling of ONE sharded RAM: an op on N*2^k entries counts as N ops of the 2^k-entry metric
     weight = world if (sharded and not strong) else 1
     log_entries = int(np.log2(max_addr)) if max_addr & (max_addr - 1) == 0 else float(np.log2(max_addr))
-    a_read, a_rpw, a_write = algorithmic_bytes(max_addr, ws, n_digits)
+    a_read, a_rpw, a_write = algorithmic_bytes(max_addr, ws, n_digits, atk_i64)
     cnt = op_counts(max_addr, ws, p.base2d())
     if mode == "replicas":
         par = f"{world} independent RAMs of 2^{args.log_max_addr} entries, one per GPU, no data-path collective"
@@ -402,7 +410,9 @@ def main():
         "arithmetic": "exact integers mod 2^48+57345 carried in FP64 (error-free products); int32 limbs in HBM",
         "data": "synthetic",
         "config": {"workload": f"Ram::read + Ram::read_prepare_write + Ram::write, MAX_ADDR=2^{log_entries}, "
-                               f"WORDSIZE={ws}, N=4096, base2k=17, rank=1 (BASELINE.json configs[2]+[3]"
+                               f"WORDSIZE={ws}, N=4096, base2k=17, rank=1, "
+                               + ("README.md:17-27 parameter block (K_PT=9, K_EVK=85: 5-limb trace keys)" if crypto else "source constants (parameters.rs:11-18)")
+                               + " (BASELINE.json configs[2]+[3]"
                                + ("; configs[4] sharding" if sharded else "") + ")",
                    "rams": n_rams, "rows_per_subram": cnt["rows"], "parallelism": par},
         "ram_ops_s_raw": raw_ops_per_s,
@@ -415,7 +425,15 @@ def main():
         "algorithmic_GBs_per_op": {"read": a_read / read_ms / 1e6, "read_prepare_write": a_rpw / rpw_ms / 1e6,
                                    "write": a_write / write_ms / 1e6},
         "reference_published": {"read_ms": 450, "write_ms": 1200, "hw": "i9-12900K single thread (README.md:36), 2^18 entries",
-                                "speedup_read": 450.0 / read_ms, "speedup_write": 1200.0 / write_ms},
+                                "speedup_read": 450.0 / read_ms, "speedup_write": 1200.0 / write_ms,
+                                "speedup_rpw_plus_write": (450.0 + 1200.0) / (rpw_ms + write_ms),
+                                "same_parameter_block": bool(crypto),
+                                "note": ("measured on the README's own parameter block" if crypto else
+                                         "the published numbers were taken with the README block (5-limb trace keys; run --params readme for the "
+                                         "like-for-like ratio); these ratios are against the cheaper source constants")
+                                        + "; call for call as the example times them (examples/fhe-ram.rs:98-154); Ram::write here resumes from "
+                                          "what read_prepare_write kept, so speedup_rpw_plus_write (a read_prepare_write priced as a published "
+                                          "read) is the fairer write figure"},
         "trace_tail": dict(tail, note="trace chains at the end of a read run as one launch with in-kernel hand-offs; `fallbacks` of them "
                                       "gave up (CUs not available side by side) and were redone by the fused launch behind them"),
         "device": ram.device_info(),
@@ -440,9 +458,9 @@ def main():
         if kf["launches"]:
             avg_ms = kf["ms"] / kf["launches"]
             blocks = kf["blocks"] / kf["launches"]
-            bytes_abi = blocks * 2 * GLWE_I64 + ATK_I64              # in + out GLWE (int64 limbs) + key once
-            bytes_dev = blocks * 2 * (GLWE_I64 // 2) + ATK_I64       # what the device layout must move: int32 limbs, f64 key
-            ach = kf["blocks"] * FP64_PER_KS / (kf["ms"] * 1e-3) / 1e12          # T FP64 VALU instructions / s
+            bytes_abi = blocks * 2 * GLWE_I64 + atk_i64              # in + out GLWE (int64 limbs) + key once
+            bytes_dev = blocks * 2 * (GLWE_I64 // 2) + atk_i64       # what the device layout must move: int32 limbs, f64 key
+            ach = kf["blocks"] * fp64_per_ks / (kf["ms"] * 1e-3) / 1e12          # T FP64 VALU instructions / s
             chain = classes["keyswitch_chain_launch"]
             # PRIMARY roofline = the roof that binds this kernel: the FP64 vector ALU.  Every FP64 VALU instruction
             # (mul / add / fma / rndne: all issue at the FMA rate) is priced as one FMA slot = 2 FLOP, so that achieved
@@ -451,7 +469,7 @@ def main():
                                "bound": "valu_fp64", "achieved": 2 * ach, "peak": 2 * FP64_VALU_PEAK_TINSTR, "unit": "TFLOP/s",
                                "frac": ach / FP64_VALU_PEAK_TINSTR,
                                "achieved_T_fp64_instr_s": ach, "peak_T_fp64_instr_s": FP64_VALU_PEAK_TINSTR,
-                               "fp64_instr_per_keyswitch": FP64_PER_KS,
+                               "fp64_instr_per_keyswitch": fp64_per_ks,
                                "traffic": pmc_traffic_per_launch(),
                                "traffic_source": PMC_PROFILE + " (HBM bytes per step of this kernel: separate rocprofv3 --pmc FETCH_SIZE / "
                                                  "WRITE_SIZE passes of this command, FETCH_SIZE scaled by the factor calibrated on a "
@@ -467,7 +485,7 @@ def main():
                                                              "wave-instruction per SIMD at the 2.15 GHz clock of FP64 load)"}
             ks = classes["keyswitch"]
             if ks["launches"]:
-                cls = ks["blocks"] * FP64_PER_KS / (ks["ms"] * 1e-3) / 1e12
+                cls = ks["blocks"] * fp64_per_ks / (ks["ms"] * 1e-3) / 1e12
                 out["roofline"]["whole_class"] = {"achieved_T_fp64_instr_s": cls, "frac": cls / FP64_VALU_PEAK_TINSTR,
                                                   "avg_launch_ms": ks["ms"] / ks["launches"], "avg_blocks_per_launch": ks["blocks"] / ks["launches"]}
             # SECONDARY: the same launches against HBM.  frac is on the bytes the DEVICE layout must move (int32 limbs, f64
@@ -484,7 +502,7 @@ def main():
         ks_ref = 2 * cnt["ks_read"] + cnt["ks_write"]
         L0 = max(0, 12 - max(0, (cnt["rows"] - 1).bit_length())) if cnt["rows"] > 1 else 0
         ks_exec = ks_ref - (ws * 12 + ws * cnt["rows"] * L0)     # the write resumes from what read_prepare_write kept (csrc/path.hpp)
-        fp_step = ep_ref * FP64_PER_EP + ks_exec * FP64_PER_KS
+        fp_step = ep_ref * FP64_PER_EP + ks_exec * fp64_per_ks
         out["roofline_whole_op"] = {"what": "one step = read + read_prepare_write + write, device-resident, against the same two roofs",
                                     "hbm": {"algorithmic_bytes_per_step": a_read + a_rpw + a_write,
                                             "achieved_GBs": (a_read + a_rpw + a_write) / ms_per_step / 1e6,
@@ -504,7 +522,7 @@ def main():
         # ws (the reference processes them one after the other, ram.rs:187-190; prepare_inv is shared, <1 % of a write)
         whole = max_addr * ws <= (1 << 20)
         k = 1 if whole else ws
-        r, q, w = cpu_baseline(max_addr, ws if whole else 1, 99, 1)
+        r, q, w = cpu_baseline(max_addr, ws if whole else 1, 99, 1, crypto)
         out["cpu_baseline"] = {"value": 2.0 / (k * (r + q + w)), "unit": "RAM ops/s", "cores": 1, "kind": "port",
                                "sample": "oracle (C++ exact-integer restatement), single thread, "
                                          + (f"the whole 2^{args.log_max_addr} x {ws}-byte RAM, one step: " if whole else
@@ -513,7 +531,7 @@ def main():
                                "read_ms": k * r * 1e3, "read_prepare_write_ms": k * q * 1e3, "write_ms": k * w * 1e3,
                                "host_cpu": host_cpu()}
         cores = host_cores()
-        r, q, w = cpu_baseline(max_addr, ws, 99, cores)
+        r, q, w = cpu_baseline(max_addr, ws, 99, cores, crypto)
         out["cpu_baseline_allcores"] = {"value": 2.0 / (r + q + w), "unit": "RAM ops/s", "cores": cores, "kind": "port",
                                         "sample": f"oracle, OpenMP over the {ws} sub-RAMs and over the rows (per-row loops; packing level by level with "
                                                   f"the leaves of a level in parallel), whole 2^{args.log_max_addr} RAM, one step",

@@ -154,18 +154,27 @@ def galois_elements(log_n: int = 12) -> List[int]:
 
 
 class Parameters:
-    """parameters.rs:147-176.  Defaults are the source constants (parameters.rs:11-21)."""
+    """parameters.rs:147-176.  Defaults are the source constants (parameters.rs:11-21).  The layout factories of the
+    reference are generic in every precision (parameters.rs:53-104); the kernels accept any precision inside the limb
+    counts of its two published blocks (source constants and README.md:17-27)."""
 
-    def __init__(self, max_addr: int = 1 << 14, decomp_n: Sequence[int] = (3, 3, 3, 3), word_size: int = 4):
+    def __init__(self, max_addr: int = 1 << 14, decomp_n: Sequence[int] = (3, 3, 3, 3), word_size: int = 4,
+                 k_glwe_pt: int = 3, k_glwe_ct: int = 51, k_ggsw_addr: int = 68, k_evk_trace: int = 68, k_evk_ggsw_inv: int = 85):
         self.log_n, self._base2k, self._rank = 12, 17, 1
-        self._k_glwe_pt, self._k_glwe_ct, self._k_ggsw_addr = 3, 51, 68
-        self._k_evk_trace, self._k_evk_ggsw_inv = 68, 85
+        self._k_glwe_pt, self._k_glwe_ct, self._k_ggsw_addr = int(k_glwe_pt), int(k_glwe_ct), int(k_ggsw_addr)
+        self._k_evk_trace, self._k_evk_ggsw_inv = int(k_evk_trace), int(k_evk_ggsw_inv)
         assert sum(decomp_n) == self.log_n  # parameters.rs:168
         self._max_addr, self._decomp_n, self._word_size = int(max_addr), [int(x) for x in decomp_n], int(word_size)
 
     @classmethod
     def new(cls):  # parameters.rs:167
         return cls()
+
+    @classmethod
+    def readme(cls, max_addr: int = 1 << 18, word_size: int = 4):
+        """The parameter block of README.md:17-34, with which the published 450 ms / 1200 ms were taken:
+        K_PT = 9, K_CT = 3*17, K_ADDR = 4*17, K_EVK = 5*17 for EVERY evaluation key (5-limb trace keys), MAX_ADDR = 2^18."""
+        return cls(max_addr=max_addr, word_size=word_size, k_glwe_pt=9, k_evk_trace=85, k_evk_ggsw_inv=85)
 
     def n(self):
         return 1 << self.log_n
@@ -222,6 +231,8 @@ class Parameters:
     def _c(self) -> _CParams:
         cp = _CParams()
         library().fheram_params_default(C.byref(cp))
+        cp.k_glwe_pt, cp.k_glwe_ct, cp.k_ggsw_addr = self._k_glwe_pt, self._k_glwe_ct, self._k_ggsw_addr
+        cp.k_evk_trace, cp.k_evk_ggsw_inv = self._k_evk_trace, self._k_evk_ggsw_inv
         cp.max_addr = self._max_addr
         cp.word_size = self._word_size
         cp.n_decomp = len(self._decomp_n)
@@ -408,6 +419,16 @@ def cast_u8_to_signed(value: int, bit_length: int) -> int:
     return v >> shift
 
 
+def expected_plain(value: int, k_pt: int, written: bool = False) -> int:
+    """cast_u8_to_signed generalised to any plaintext precision (README.md:20 has K_PT = 9, beyond the 8 bits the example's
+    helper asserts): Ram::encrypt_sk encodes `(x as i8) as i64` (ram.rs:361-363), encrypt_glwe `value as i64`
+    (examples/fhe-ram.rs:196); the torus keeps either mod 2^k_pt, centred."""
+    v = int(value) if written else (int(value) - 256 if int(value) >= 128 else int(value))
+    m = 1 << k_pt
+    v %= m
+    return v - m if v >= m // 2 else v
+
+
 def encode_coeff(value: int, k: int, base2k: int = 17):
     """encode_coeff_i64(value, k, idx): value * 2^-k on ceil(k/base2k) normalised limbs"""
     size = -(-k // base2k)
@@ -465,8 +486,9 @@ class Ram:
         return cls(Parameters.new(), device)
 
     @classmethod
-    def new_from_ram_params(cls, word_size: int, decomp_n: Sequence[int], max_addr: int, device: int = 0):  # ram.rs:72
-        return cls(Parameters(max_addr=max_addr, decomp_n=decomp_n, word_size=word_size), device)
+    def new_from_ram_params(cls, word_size: int, decomp_n: Sequence[int], max_addr: int, device: int = 0, **crypto):  # ram.rs:72
+        """crypto: k_glwe_pt / k_evk_trace / ... (CryptographicParameters, parameters.rs:23-32), default = source constants"""
+        return cls(Parameters(max_addr=max_addr, decomp_n=decomp_n, word_size=word_size, **crypto), device)
 
     def __del__(self):
         if getattr(self, "_h", None) and _LIB is not None:
@@ -484,6 +506,10 @@ class Ram:
             raise FheRamError(5, "these keys were generated on another context's device (EvaluationKeysPrepared.encrypt_sk "
                                  "without keep_std=True): their std forms are not on the host")
         L = library()
+        atk_len, inv_len = L.fheram_atk_len(self._h), L.fheram_evk_inv_len(self._h)
+        if any(k.size != atk_len for k in keys.atk_glwe) or keys.atk_ggsw_inv.size != inv_len or keys.tsk_ggsw_inv.size != inv_len:
+            raise FheRamError(1, f"evaluation-key layout does not match the context's (trace keys of {atk_len} limbs-elements, "
+                                 f"inverse / tensor keys of {inv_len}: evk_glwe_infos / evk_ggsw_infos, parameters.rs:71-93)")
         arr = (I64P * len(keys.atk_glwe))(*[_p(k) for k in keys.atk_glwe])
         self._chk(L.fheram_keys_load(self._h, _p(keys.gal_els), len(keys.gal_els), arr, _p(keys.atk_ggsw_inv),
                                      keys.atk_ggsw_inv_p, _p(keys.tsk_ggsw_inv)))

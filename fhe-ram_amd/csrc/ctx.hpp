@@ -69,11 +69,12 @@ struct fheram_ctx {
     size_t rows_glob = 0;   // rows per sub-RAM of the whole RAM
     int shard = 0, n_shards = 1;   // row sharding: this context owns rows r = shard (mod n_shards)
     std::vector<std::vector<int>> base2d;
-    static constexpr int S_CT = 3, S_ADDR = 4, S_EVK = 4, S_INV = 5, DNUM_CT = 3, DNUM_GGSW = 4;
+    static constexpr int S_CT = 3, S_ADDR = 4, S_INV = 5, DNUM_CT = 3, DNUM_GGSW = 4;
+    int s_evk = 4;          // limbs of a trace / packing key: ceil(k_evk_trace / base2k) = 4 (source constants, parameters.rs:17) or 5 (README.md:17-27: K_EVK = 5 * BASEK)
+    size_t atk = 0;         // elements of one trace key: DNUM_CT * s_evk * 2 * N   (evk_glwe_infos, parameters.rs:71-81)
     static constexpr size_t GLWE = (size_t)S_CT * 2 * N;                   // elements of a ct
     static constexpr size_t GLWE4 = (size_t)S_ADDR * 2 * N;                // one GGSW row ct
     static constexpr size_t GGSW = (size_t)DNUM_CT * 2 * GLWE4;            // elements of a GGSW
-    static constexpr size_t ATK = (size_t)DNUM_CT * S_EVK * 2 * N;         // trace key
     static constexpr size_t EVK5 = (size_t)DNUM_GGSW * S_INV * 2 * N;      // inverse / tensor key
     static constexpr size_t GGSW5 = (size_t)DNUM_GGSW * 2 * S_INV * 2 * N; // one bit of an FheUint (N4)
     // device

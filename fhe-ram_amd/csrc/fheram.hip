@@ -30,10 +30,15 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     *out = nullptr;
     if (n_shards < 1 || shard < 0 || shard >= n_shards || (n_shards & (n_shards - 1)) != 0)
         return fail(nullptr, FHERAM_ERR_INVALID_ARG, "n_shards must be a power of two and 0 <= shard < n_shards");
-    // The kernels are built for the reference's cryptographic parameters (parameters.rs:11-18).
-    if (p->log_n != 12 || p->base2k != 17 || p->rank != 1 || p->k_glwe_ct != 51 || p->k_ggsw_addr != 68 ||
-        p->k_evk_trace != 68 || p->k_evk_ggsw_inv != 85)
-        return fail(nullptr, FHERAM_ERR_UNSUPPORTED, "kernels are built for LOG_N=12, BASE2K=17, RANK=1, K_CT=51, K_ADDR=68, K_EVK=68/85");
+    // The kernels are built for the limb counts of the reference's two published parameter blocks: the source constants
+    // (parameters.rs:11-18: trace keys at 4 limbs) and the README block its timings were taken with (README.md:17-27:
+    // K_EVK = 5 * BASEK for every evaluation key, K_PT = 9).  Precisions are accepted anywhere inside those limb counts.
+    auto limbs = [&](uint32_t k) { return (k + p->base2k - 1) / (p->base2k ? p->base2k : 1); };
+    if (p->log_n != 12 || p->base2k != 17 || p->rank != 1 || p->k_glwe_ct == 0 || limbs(p->k_glwe_ct) != 3 || limbs(p->k_ggsw_addr) != 4 ||
+        (limbs(p->k_evk_trace) != 4 && limbs(p->k_evk_trace) != 5) || limbs(p->k_evk_ggsw_inv) != 5)
+        return fail(nullptr, FHERAM_ERR_UNSUPPORTED, "kernels are built for LOG_N=12, BASE2K=17, RANK=1 and limb counts K_CT: 3, K_ADDR: 4, K_EVK_TRACE: 4 or 5, K_EVK_GGSW_INV: 5");
+    if (p->k_glwe_pt == 0 || p->k_glwe_pt > p->k_glwe_ct)
+        return fail(nullptr, FHERAM_ERR_INVALID_ARG, "k_glwe_pt must be in [1, k_glwe_ct]");
     if (p->word_size == 0 || p->word_size > 64 || p->n_decomp == 0 || p->n_decomp > 16 || p->max_addr < 2)
         return fail(nullptr, FHERAM_ERR_INVALID_ARG, "bad word_size / decomp_n / max_addr");
     unsigned sum = 0;
@@ -48,6 +53,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
 
     fheram_ctx* c = new fheram_ctx();
     c->p = *p; c->device = device; c->ws = (int)p->word_size;
+    c->s_evk = (int)limbs(p->k_evk_trace);
+    c->atk = (size_t)fheram_ctx::DNUM_CT * c->s_evk * 2 * N;
     c->rows_glob = (size_t)((p->max_addr + N - 1) / N);
     c->shard = shard; c->n_shards = n_shards;
     if (n_shards > 1 && ((c->rows_glob & (c->rows_glob - 1)) != 0 || c->rows_glob < (size_t)n_shards)) {
@@ -138,6 +145,13 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR_KS4(KS_PAIR, 3, 4, 3);
     LDSATTR_KS(KS_ADD, 3, 4, 3);
     LDSATTR_KS(KS_SUBNEG, 3, 4, 3);
+    LDSATTR((&k_keyswitch_chain<3, 5, 3>));
+    LDSATTR((&k_trace_tail<3, 5, 3>));
+    LDSATTR_KS(KS_AUTO, 3, 5, 3);
+    LDSATTR_KS(KS_TRACE, 3, 5, 3);
+    LDSATTR_KS4(KS_PAIR, 3, 5, 3);
+    LDSATTR_KS(KS_ADD, 3, 5, 3);
+    LDSATTR_KS(KS_SUBNEG, 3, 5, 3);
     LDSATTR_KS4(KS_AUTO, 4, 5, 4);
     LDSATTR_KS4(KS_TENSOR, 4, 5, 4);
     LDSATTR((&k_encrypt_sk<1, 1>));
@@ -153,7 +167,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMalloc(&c->d_tw, N * sizeof(double)));
     CCHK(hipMemcpy(c->d_tw, tw.data(), N * sizeof(double), hipMemcpyHostToDevice));
     const size_t G = fheram_ctx::GLWE, nrow = (size_t)c->ws * c->rows;
-    CCHK(hipMalloc(&c->d_atk, (size_t)LOGN * fheram_ctx::ATK * sizeof(double)));
+    CCHK(hipMalloc(&c->d_atk, (size_t)LOGN * c->atk * sizeof(double)));
     CCHK(hipMalloc(&c->d_atk_inv, fheram_ctx::EVK5 * sizeof(double)));
     CCHK(hipMalloc(&c->d_tsk, fheram_ctx::EVK5 * sizeof(double)));
     CCHK(hipMalloc(&c->d_data, nrow * G * sizeof(int32_t)));
@@ -214,7 +228,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
 
 size_t fheram_glwe_len(const fheram_ctx*) { return fheram_ctx::GLWE; }
 size_t fheram_ggsw_len(const fheram_ctx*) { return fheram_ctx::GGSW; }
-size_t fheram_atk_len(const fheram_ctx*) { return fheram_ctx::ATK; }
+size_t fheram_atk_len(const fheram_ctx* c) { return c ? c->atk : 0; }
 size_t fheram_evk_inv_len(const fheram_ctx*) { return fheram_ctx::EVK5; }
 size_t fheram_rows(const fheram_ctx* c) { return c ? c->rows : 0; }
 int fheram_n_digits(const fheram_ctx* c) { return c ? c->n_digits : 0; }
@@ -237,12 +251,12 @@ int fheram_keys_load(fheram_ctx* c, const int64_t* gal_els, int n_gal, const int
         if (order[i] < 0) return fail(c, FHERAM_ERR_KEYS, "missing trace key for a Galois element of GLWE::trace_galois_elements");
     }
     int32_t* d_stage = nullptr;
-    const size_t stage_n = std::max(fheram_ctx::ATK, fheram_ctx::EVK5);
+    const size_t stage_n = std::max(c->atk, fheram_ctx::EVK5);
     HIPCHK(c, hipMalloc(&d_stage, stage_n * sizeof(int32_t)));
     int rc = FHERAM_OK;
     for (int i = 0; i < LOGN && rc == FHERAM_OK; i++) {
-        rc = upload_i64(c, d_stage, atk_glwe[order[i]], fheram_ctx::ATK);
-        if (rc == FHERAM_OK) launch_prepare(c, d_stage, c->d_atk + (size_t)i * fheram_ctx::ATK, (int)(fheram_ctx::ATK / N), c->gal[i]);
+        rc = upload_i64(c, d_stage, atk_glwe[order[i]], c->atk);
+        if (rc == FHERAM_OK) launch_prepare(c, d_stage, c->d_atk + (size_t)i * c->atk, (int)(c->atk / N), c->gal[i]);
         hipStreamSynchronize(c->stream);
     }
     if (rc == FHERAM_OK) rc = upload_i64(c, d_stage, atk_ggsw_inv, fheram_ctx::EVK5);
@@ -530,9 +544,9 @@ int fheram_glwe_automorphism(fheram_ctx* c, int mode, int64_t gal_el, const int6
     int rc = upload_i64(c, da.p, a, (size_t)batch * G);
     if (rc != FHERAM_OK) return rc;
     KsArgs ka = ks_args(c, ref(da.p, 0, (long)G), ref(da.p, 0, 0), ref(dout.p, 0, (long)G), trace_key(c, ki), gal_el);
-    if (mode == 0) launch_ks<KS_AUTO, 3, 4, 3>(c, ka, batch, 1);
-    else if (mode == 1) launch_ks<KS_ADD, 3, 4, 3>(c, ka, batch, 1);
-    else launch_ks<KS_SUBNEG, 3, 4, 3>(c, ka, batch, 1);
+    if (mode == 0) launch_ks_tr<KS_AUTO>(c, ka, batch, 1);
+    else if (mode == 1) launch_ks_tr<KS_ADD>(c, ka, batch, 1);
+    else launch_ks_tr<KS_SUBNEG>(c, ka, batch, 1);
     HIPCHK(c, hipGetLastError());
     return download_i64(c, res, dout.p, (size_t)batch * G);
 }

@@ -91,7 +91,13 @@ KsArgs ks_args(fheram_ctx* c, GlweRef a, GlweRef b, GlweRef out, const double* k
     ka.g = galois_mod(gal); ka.ginv = galois_inv_mod(ka.g); ka.t = t; ka.rot_mul = rot_mul; ka.rot_base = rot_base; ka.big = c->d_big;
     return ka;
 }
-const double* trace_key(fheram_ctx* c, int i) { return c->d_atk + (size_t)i * fheram_ctx::ATK; }
+const double* trace_key(fheram_ctx* c, int i) { return c->d_atk + (size_t)i * c->atk; }
+// the automorphism family on RAM ciphertexts (3 limbs) with a trace key of the context's size (4 or 5 limbs)
+template <int MODE>
+void launch_ks_tr(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
+    if (c->s_evk == 5) launch_ks<MODE, 3, 5, 3>(c, ka, gx, gy);
+    else launch_ks<MODE, 3, 4, 3>(c, ka, gx, gy);
+}
 bool same(const GlweRef& a, const GlweRef& b) { return a.p == b.p; }
 
 // Runs n dependent out-of-place steps src -> ... -> dst, alternating between dst and tmp so that
@@ -154,13 +160,15 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
     for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
-    hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+    if (c->s_evk == 5) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+    else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
 }
 // The latency-bound end of the path (at most 8 ciphertexts, one per XCD): n trace steps as ONE launch with in-kernel
 // hand-offs (k_trace_tail), followed by the fused chain launch that only runs if that one gave up.
 bool use_tail(const fheram_ctx* c, int n, int gx, int gy) {
     return c->tail && c->limb_split && c->fine_split && n >= 2 && n <= CHAIN_MAX && (long)gx * gy <= TAIL_GROUPS &&
            c->cur == c->stream &&            // every launch of a context shares d_tail_sync: main stream only
+           2 * c->s_evk * 3 <= 32 &&         // the workgroups of a ciphertext fit the 32 CUs of one XCD (24 with 4-limb keys, 30 with 5)
            c->cus >= TAIL_GROUPS * 32 &&     // the whole chip (8 XCDs x 32 CUs): a partition could not hold the groups side by side
            !(c->use_graph && !c->profile);   // a captured launch would replay its generation number
 }
@@ -183,8 +191,13 @@ void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int st
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
     ca.pred = c->d_tail_sync + TAIL_GROUPS * 32; ca.pred_seq = ta.seq; ca.host_count = c->h_tail_fb;
     for (int i = 0; i < n; i++) { ta.key[i] = ca.key[i] = trace_key(c, start + i); ta.ginv[i] = ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
-    hipLaunchKernelGGL((k_trace_tail<3, 4, 3>), dim3(TAIL_GROUPS * 2 * 4 * 3), dim3(T), LDS_BYTES, c->cur, ta);
-    hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+    if (c->s_evk == 5) {
+        hipLaunchKernelGGL((k_trace_tail<3, 5, 3>), dim3(TAIL_GROUPS * 2 * 5 * 3), dim3(T), LDS_BYTES, c->cur, ta);
+        hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+    } else {
+        hipLaunchKernelGGL((k_trace_tail<3, 4, 3>), dim3(TAIL_GROUPS * 2 * 4 * 3), dim3(T), LDS_BYTES, c->cur, ta);
+        hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+    }
 }
 // GLWE::trace(start, end): step i = rsh(1) then a += phi_{g_i}(KS(a)).
 // The first step may read its input rotated by X^-(x*rot_mul) (write path, ram.rs:621,629).
@@ -196,7 +209,7 @@ void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start
         GlweRef b[2];
         if (chain_bufs(n, src, dst, tmp, b) && !same(b[1], src)) { launch_trace_tail(c, src, b, start, n, gx, gy); return; }
     }
-    if (use_chain(c, n, gx, gy, 4) && !use_fine_split(c, gx, gy, 2 * 4 * 3)) {
+    if (use_chain(c, n, gx, gy, c->s_evk) && !use_fine_split(c, gx, gy, 2 * c->s_evk * 3)) {
         GlweRef b[2];
         if (chain_bufs(n, src, dst, tmp, b)) { launch_trace_chain(c, src, b, start, n, gx, gy, rot_mul, rot_base); return; }
         if (chain_bufs(n, src, tmp, dst, b)) {
@@ -207,7 +220,7 @@ void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start
     }
     run_chain(c, end - start, src, dst, tmp, gx, gy, [&](int i, GlweRef in, GlweRef out) {
         KsArgs ka = ks_args(c, in, in, out, trace_key(c, start + i), c->gal[start + i], 0, i == 0 ? rot_mul : 0, i == 0 ? rot_base : 0);
-        launch_ks<KS_TRACE, 3, 4, 3>(c, ka, gx, gy);
+        launch_ks_tr<KS_TRACE>(c, ka, gx, gy);
     });
 }
 // GLWEPacker (ram.rs:425-448), level-synchronous, over `count` leaves per y at
@@ -230,7 +243,7 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
         trace_steps(c, ref(src, sy, sx), ref(A, sy, sx), ref(B, sy, sx), 0, n_alone, (int)count, gy);
         cur = A;
     } else
-    if (count > 0 && use_chain(c, n_alone, (int)count, gy, 4) && !use_fine_split(c, (int)count, gy, 2 * 4 * 3)) {
+    if (count > 0 && use_chain(c, n_alone, (int)count, gy, c->s_evk) && !use_fine_split(c, (int)count, gy, 2 * c->s_evk * 3)) {
         int32_t* b0 = other(cur);
         int32_t* b1 = other(b0);
         const GlweRef b[2] = {ref(b0, sy, sx), ref(b1, sy, sx)};
@@ -240,7 +253,7 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
     for (int i = 0; i < n_alone; i++) {
         int32_t* nxt = other(cur);
         KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i]);
-        launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)count, gy);
+        launch_ks_tr<KS_TRACE>(c, ka, (int)count, gy);
         cur = nxt;
     }
     size_t live = count;
@@ -252,11 +265,11 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
         const long n_alone_here = std::min<long>(h, (long)live) - n_pair;
         if (n_pair > 0) {
             KsArgs ka = ks_args(c, ref(cur, sy, sx), ref(cur + h * sx, sy, sx), ref(nxt, sy, sx), trace_key(c, i), c->gal[i], N >> (i + 1));
-            launch_ks<KS_PAIR, 3, 4, 3>(c, ka, (int)n_pair, gy);
+            launch_ks_tr<KS_PAIR>(c, ka, (int)n_pair, gy);
         }
         if (n_alone_here > 0) {
             KsArgs ka = ks_args(c, ref(cur + n_pair * sx, sy, sx), ref(cur, sy, sx), ref(nxt + n_pair * sx, sy, sx), trace_key(c, i), c->gal[i]);
-            launch_ks<KS_TRACE, 3, 4, 3>(c, ka, (int)n_alone_here, gy);
+            launch_ks_tr<KS_TRACE>(c, ka, (int)n_alone_here, gy);
         }
         live = std::min<size_t>(live, (size_t)h);
         cur = nxt;

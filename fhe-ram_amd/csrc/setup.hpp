@@ -293,7 +293,7 @@ int fheram_address_download(fheram_ctx* c, const fheram_addr* a, int64_t* out) {
 int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t* mask, const int64_t* noise, int64_t* std_out) {
     if (!c) return FHERAM_ERR_INVALID_ARG;
     if (!mask || !noise) return fail(c, FHERAM_ERR_INVALID_ARG, "null argument");
-    int rc = check_setup_args(c, sk, fheram_ctx::S_EVK, (int)c->p.k_evk_trace);
+    int rc = check_setup_args(c, sk, c->s_evk, (int)c->p.k_evk_trace);
     if (rc == FHERAM_OK) rc = check_setup_args(c, sk, fheram_ctx::S_INV, (int)c->p.k_evk_ggsw_inv);
     if (rc != FHERAM_OK) return rc;
     HIPCHK(c, hipSetDevice(c->device));
@@ -302,7 +302,7 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     c->cur = c->stream;
     int32_t *d_stage = nullptr, *d_small = nullptr;
     double* d_hat = nullptr;
-    const size_t stage_n = std::max(fheram_ctx::ATK, fheram_ctx::EVK5);
+    const size_t stage_n = std::max(c->atk, fheram_ctx::EVK5);
     HIPCHK(c, hipMalloc(&d_stage, stage_n * sizeof(int32_t)));
     hipError_t e = hipMalloc(&d_small, 2 * N * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&d_hat, N * sizeof(double));
@@ -333,8 +333,8 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
         return gglwe(sk->sk.data(), d_hat, rows, S, k, d_prepared, std_dst, p);
     };
     for (int i = 0; i < LOGN && rc == FHERAM_OK; i++)
-        rc = automorphism_key(c->gal[i], fheram_ctx::DNUM_CT, fheram_ctx::S_EVK, (int)c->p.k_evk_trace,
-                              c->d_atk + (size_t)i * fheram_ctx::ATK, std_out ? std_out + (size_t)i * fheram_ctx::ATK : nullptr);
+        rc = automorphism_key(c->gal[i], fheram_ctx::DNUM_CT, c->s_evk, (int)c->p.k_evk_trace,
+                              c->d_atk + (size_t)i * c->atk, std_out ? std_out + (size_t)i * c->atk : nullptr);
     if (rc == FHERAM_OK) {   // tensor key (rank 1): GGLWE of s*s under s (keys.rs:167-169); s*s = phase of (0, s) under s
         std::copy(sk->sk.begin(), sk->sk.end(), ss.begin() + N);
         hipMemcpyAsync(d_small, ss.data(), 2 * N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
@@ -344,10 +344,10 @@ int fheram_keys_encrypt_sk(fheram_ctx* c, const fheram_secret* sk, const int64_t
     }
     if (rc == FHERAM_OK)
         rc = gglwe(ss.data(), sk->d_hat, fheram_ctx::DNUM_GGSW, fheram_ctx::S_INV, (int)c->p.k_evk_ggsw_inv, c->d_tsk,
-                   std_out ? std_out + (size_t)LOGN * fheram_ctx::ATK : nullptr, 0);
+                   std_out ? std_out + (size_t)LOGN * c->atk : nullptr, 0);
     if (rc == FHERAM_OK)
         rc = automorphism_key(-1, fheram_ctx::DNUM_GGSW, fheram_ctx::S_INV, (int)c->p.k_evk_ggsw_inv, c->d_atk_inv,
-                              std_out ? std_out + (size_t)LOGN * fheram_ctx::ATK + fheram_ctx::EVK5 : nullptr);
+                              std_out ? std_out + (size_t)LOGN * c->atk + fheram_ctx::EVK5 : nullptr);
     hipFree(d_stage);
     wipe_free(c->stream, d_small, 2 * N * sizeof(int32_t));   // phi(s), s*s
     wipe_free(c->stream, d_hat, N * sizeof(double));

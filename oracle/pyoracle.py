@@ -374,6 +374,17 @@ class Oracle:
     def cast_u8_to_signed(v, bits):
         return int(lib().fo_cast_u8_to_signed(v, bits))
 
+    @staticmethod
+    def expected_plain(value, k_pt, written=False):
+        """What coefficient 0 decrypts to at plaintext precision k_pt: Ram::encrypt_sk encodes `(x as i8) as i64`
+        (ram.rs:361-363), the example's encrypt_glwe encodes `value as i64` (examples/fhe-ram.rs:196); the torus keeps
+        either mod 2^k_pt, centred.  For k_pt <= 8 both are cast_u8_to_signed (examples/fhe-ram.rs:25-32, which asserts
+        bit_length <= 8); this is the same rule for the README's K_PT = 9 (README.md:20)."""
+        v = int(value) if written else (int(value) - 256 if int(value) >= 128 else int(value))
+        m = 1 << k_pt
+        v %= m
+        return v - m if v >= m // 2 else v
+
     # -- handles
     def keys_prepare(self, evk):
         atk = np.ascontiguousarray(evk["atk_glwe"])

@@ -16,6 +16,9 @@ itself stays unpinned (oracle/README.md).
       (MAX_ADDR = 2^12, 2^14 and the full BASELINE.json sizes 2^18 and 2^21, WORDSIZE = 4), inputs
       regenerated from the recorded seeds.  The two full sizes run the oracle's all-core variant
       (same results as one thread, tests/test_oracle.py); 2^21 takes a few minutes on 8 cores.
+      Keys "readme_*": the same flow with the parameter block of the reference's README (README.md:17-27:
+      K_PT = 9, K_EVK = 85, i.e. 5-limb trace keys — what its published 450 / 1200 ms were taken with).
+      `--readme-only` regenerates just those.
 
 Run from the repo root:  python tests/golden/make_golden.py [--small-only]
 """
@@ -78,12 +81,12 @@ def flow(params, seed, threads=1):
     # decrypt checks (the reference's own assertion) so a fixture can never freeze a wrong answer
     newdata = data.copy()
     for i in range(p.word_size):
-        want = o.cast_u8_to_signed(int(data[i + p.word_size * idx]), p.k_glwe_pt)
+        want = o.expected_plain(int(data[i + p.word_size * idx]), p.k_glwe_pt)
         for key in ("read", "rpw"):
             v, nz = o.glwe_decrypt(out[key][i], want, sk)
             assert v == want and nz < -(p.k_glwe_pt + 1), (key, v, want, nz)
         newdata[i + p.word_size * idx] = val[i]
-        want = o.cast_u8_to_signed(int(val[i]), p.k_glwe_pt)
+        want = o.expected_plain(int(val[i]), p.k_glwe_pt, written=True)
         v, nz = o.glwe_decrypt(out["readback"][i], want, sk)
         assert v == want and nz < -(p.k_glwe_pt + 1), ("readback", v, want, nz)
     return inp, out, o
@@ -122,15 +125,20 @@ def main():
     json.dump(znx_kat(), open(os.path.join(HERE, "znx_kat.json"), "w"))
     path = os.path.join(HERE, "digests_n4096.json")
     dig = json.load(open(path)) if os.path.exists(path) else {}
-    sizes = [(1 << 12, 4, 3000), (1 << 14, 2, 4000)]
+    # (key, max_addr, word_size, seed, cryptographic parameters other than the source constants)
+    README = {"k_glwe_pt": 9, "k_evk_trace": 85}                # README.md:17-27: K_PT = 9, K_EVK = 5 * BASEK for every key
+    sizes = [("4096", 1 << 12, 4, 3000, {}), ("16384", 1 << 14, 2, 4000, {}), ("readme_16384", 1 << 14, 4, 7000, README)]
     if "--small-only" not in sys.argv:
-        sizes += [(1 << 18, 4, 5000), (1 << 21, 4, 6000)]     # BASELINE.json configs[2..4]
-    for max_addr, ws, seed in sizes:
-        inp, out, o = flow(po.OParams(max_addr=max_addr, word_size=ws), seed, threads=os.cpu_count() or 1)
-        dig[str(max_addr)] = {"word_size": ws, "seed": seed, "max_big_log2": float(np.log2(o.max_big())),
-                              "inputs": {k: sha(v) for k, v in inp.items()}, "outputs": {k: sha(v) for k, v in out.items()}}
+        sizes += [("262144", 1 << 18, 4, 5000, {}), ("2097152", 1 << 21, 4, 6000, {}),     # BASELINE.json configs[2..4]
+                  ("readme_262144", 1 << 18, 4, 8000, README)]                              # the block the published timings used
+    if "--readme-only" in sys.argv:
+        sizes = [s_ for s_ in sizes if s_[0].startswith("readme")]
+    for key, max_addr, ws, seed, crypto in sizes:
+        inp, out, o = flow(po.OParams(max_addr=max_addr, word_size=ws, **crypto), seed, threads=os.cpu_count() or 1)
+        dig[key] = {"max_addr": max_addr, "word_size": ws, "seed": seed, "params": crypto, "max_big_log2": float(np.log2(o.max_big())),
+                    "inputs": {k: sha(v) for k, v in inp.items()}, "outputs": {k: sha(v) for k, v in out.items()}}
         json.dump(dig, open(path, "w"), indent=1)
-        print("digests for max_addr", max_addr, "done", flush=True)
+        print("digests for", key, "done", flush=True)
     print("golden fixtures written to", HERE)
 
 

@@ -27,26 +27,32 @@ def sha(a):
 _INPUTS = {}
 
 
-def golden_inputs(po, max_addr):
-    """inputs of the committed flow, regenerated from its seeds (setup side of the oracle only)"""
-    if max_addr in _INPUTS:
-        return _INPUTS[max_addr]
+def golden_inputs(po, key):
+    """inputs of the committed flow `key` (MAX_ADDR, or "readme_<MAX_ADDR>" for the README parameter block),
+    regenerated from its seeds (setup side of the oracle only)"""
+    key = str(key)
+    if key in _INPUTS:
+        return _INPUTS[key]
     sys.path.insert(0, GOLD)
     import make_golden
-    d = json.load(open(os.path.join(GOLD, "digests_n4096.json")))[str(max_addr)]
-    inp = make_golden.inputs(po.OParams(max_addr=max_addr, word_size=d["word_size"]), d["seed"])
+    d = json.load(open(os.path.join(GOLD, "digests_n4096.json")))[key]
+    d.setdefault("max_addr", int(key) if key.isdigit() else None)
+    d.setdefault("params", {})
+    inp = make_golden.inputs(po.OParams(max_addr=d["max_addr"], word_size=d["word_size"], **d["params"]), d["seed"])
     assert {k: sha(v) for k, v in inp.items()} == d["inputs"], "setup side not reproducible on this machine"
     _INPUTS.clear()            # one size at a time: the 2^21 RAM is 400 MB of int64
-    _INPUTS[max_addr] = (d, inp)
+    _INPUTS[key] = (d, inp)
     return d, inp
 
 
-@pytest.mark.parametrize("max_addr", [1 << 12, 1 << 14, 1 << 18, 1 << 21])
-def test_hip_flow_matches_committed_digests(po, max_addr):
+@pytest.mark.parametrize("key", [1 << 12, 1 << 14, 1 << 18, 1 << 21, "readme_16384", "readme_262144"])
+def test_hip_flow_matches_committed_digests(po, key):
+    """"readme_*": the parameter block of the reference's README (K_PT = 9, K_EVK = 85: 5-limb trace keys), the one its
+    published timings were taken with (README.md:17-36)."""
     pkg = load_package()
-    d, inp = golden_inputs(po, max_addr)
-    ws = d["word_size"]
-    ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr)
+    d, inp = golden_inputs(po, key)
+    ws, max_addr = d["word_size"], d["max_addr"]
+    ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr, **d["params"])
     keys = pkg.EvaluationKeysPrepared(inp["gal_els"], list(inp["atk_glwe"]), inp["atk_ggsw_inv"], inp["tsk"])
     addr = pkg.Address(ram.params, list(inp["addr"]))
     ram.load_encrypted(inp["rows"])

@@ -49,13 +49,15 @@ def test_golden_flow_small_n(po, n):
     assert np.array_equal(o.evk_gen(inp["sk"], seed + 1, seed + 2)["atk_glwe"], inp["atk_glwe"])
 
 
-@pytest.mark.parametrize("max_addr", [1 << 12, 1 << 14])
-def test_golden_digests_n4096(po, max_addr):
+@pytest.mark.parametrize("key", ["4096", "16384", "readme_16384"])
+def test_golden_digests_n4096(po, key):
+    """readme_*: the parameter block of README.md:17-27 (K_PT = 9, 5-limb trace keys)"""
     import sys
     sys.path.insert(0, GOLD)
     import make_golden
-    d = json.load(open(os.path.join(GOLD, "digests_n4096.json")))[str(max_addr)]
-    inp, out, o = make_golden.flow(po.OParams(max_addr=max_addr, word_size=d["word_size"]), d["seed"])
+    d = json.load(open(os.path.join(GOLD, "digests_n4096.json")))[key]
+    max_addr = d.get("max_addr") or int(key)
+    inp, out, o = make_golden.flow(po.OParams(max_addr=max_addr, word_size=d["word_size"], **d.get("params", {})), d["seed"])
     assert {k: sha(v) for k, v in inp.items()} == d["inputs"]
     assert {k: sha(v) for k, v in out.items()} == d["outputs"]
     assert o.max_big() < 1 << 47                      # SURVEY.md A.9: exact below the HIP prime / 2
@@ -266,6 +268,6 @@ def test_committed_digests_cover_the_full_sizes():
     import json
     import os
     d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "digests_n4096.json")))
-    for size in ("4096", "16384", "262144", "2097152"):      # BASELINE.json configs[0], source default, configs[2..3], configs[4]
+    for size in ("4096", "16384", "262144", "2097152", "readme_16384", "readme_262144"):      # BASELINE.json configs[0], source default, configs[2..3], configs[4]; README.md:17-34 block
         assert {"read", "rpw", "rows_after_rpw", "rows_after_write", "readback"} <= set(d[size]["outputs"])
         assert d[size]["max_big_log2"] < 47
