@@ -209,6 +209,57 @@ def bench_ep(pkg, args):
     print(json.dumps(out))
 
 
+def bench_group(args):
+    """ONE process, N GPUs: the row-sharded RAM behind the native group handle (fheram_group_*, include/fheram.h)."""
+    from _pkg import load_package
+    pkg = load_package()
+    n, ws = args.gpus, args.word_size
+    crypto = {"k_glwe_pt": 9, "k_evk_trace": 85} if args.params == "readme" else {}
+    s_evk = 5 if crypto else 4
+    strong = args.total_log_max_addr is not None
+    max_addr = (1 << args.total_log_max_addr) if strong else (1 << args.log_max_addr) * n
+    params = pkg.Parameters(max_addr=max_addr, word_size=ws, **crypto)
+    grp = pkg.GroupRam(params, [0] * n if args.all_ranks_device0 else list(range(n)))
+    rng = np.random.default_rng(1234)
+    n_digits = params.base2d().as_1d().size()
+    keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(synth(rng, (12, 3 * s_evk * 2 * N))),
+                                      synth(rng, 4 * 5 * 2 * N), synth(rng, 4 * 5 * 2 * N))
+    addr = pkg.Address(params, list(synth(rng, (n_digits, params.ggsw_len()))))
+    grp.load_encrypted(synth(np.random.default_rng(4321), (ws, params.rows(), params.glwe_len())))
+    grp.stage_words(synth(rng, (ws, params.glwe_len())))
+    ops = (lambda: grp.read(addr, keys, download=False), lambda: grp.read_prepare_write(addr, keys, download=False),
+           lambda: grp.write(None, addr, keys))
+
+    def step():
+        ts = []
+        for fn in ops:
+            a = time.perf_counter()
+            fn()                               # group ops are synchronous: complete on every shard when they return
+            ts.append((time.perf_counter() - a) * 1e3)
+        return ts
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    per_op = np.array([step() for _ in range(args.steps)])
+    elapsed = time.perf_counter() - t0
+    read_ms, rpw_ms, write_ms = per_op.mean(axis=0)
+    weight = 1 if strong else n
+    log_entries = int(np.log2(max_addr))
+    print(json.dumps({
+        "metric": f"encrypted RAM read ops/s + write ops/s at 2^{args.log_max_addr} entries; achieved HBM GB/s vs peak",
+        "value": 2 * args.steps / elapsed * weight,
+        "unit": "RAM ops/s (1 read + 1 write[=rpw+write] per step)" + (
+            f"; an op on the {n}*2^{args.log_max_addr}-entry sharded RAM counts as {n} ops of the 2^{args.log_max_addr}-entry metric" if weight > 1 else ""),
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "mode": "group", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Ram::read + Ram::read_prepare_write + Ram::write, MAX_ADDR=2^{log_entries}, WORDSIZE={ws}, N=4096, base2k=17, rank=1"
+                               " (BASELINE.json configs[2]+[3]; configs[4] sharding)",
+                   "parallelism": f"1 process, {n} GPUs: 1 RAM of 2^{log_entries} entries, rows r = g (mod {n}) on GPU g, one host thread per GPU; "
+                                  "peer-to-peer copies: partial packs to the root per read, ct_lo to every shard per write (fheram_group_*)"},
+        "ram_ops_s_raw": 2 * args.steps / elapsed, "read_ms": read_ms, "read_prepare_write_ms": rpw_ms, "write_ms": write_ms,
+        "timing": "host wall clock per synchronous group call"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,9 +277,11 @@ def main():
                     help="cryptographic parameter block: 'source' = the constants of src/parameters.rs:11-18 (default, BASELINE.json's "
                          "'default params'); 'readme' = the block of README.md:17-27 the published 450 / 1200 ms were taken with "
                          "(K_PT = 9, K_EVK = 85: 5-limb trace keys)")
-    ap.add_argument("--mode", choices=["auto", "sharded", "replicas"], default="auto",
-                    help="N > 1: 'sharded' (default) = ONE RAM, rows sharded over the GPUs, one RCCL all-gather per read "
-                         "and one broadcast per write; 'replicas' = one independent RAM per GPU, no collective")
+    ap.add_argument("--mode", choices=["auto", "sharded", "replicas", "group"], default="auto",
+                    help="N > 1: 'sharded' (default) = ONE RAM, rows sharded over the GPUs, one process per GPU, one RCCL all-gather "
+                         "per read and one broadcast per write; 'replicas' = one independent RAM per GPU, no collective; 'group' = the "
+                         "same sharded RAM driven by ONE process through the native fheram_group_* C ABI (one host thread per GPU, "
+                         "peer-to-peer copies instead of a collective)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,6 +289,8 @@ def main():
     ap.add_argument("--no-boundary", action="store_true", help="skip the pass that includes the host hand-over")
     args = ap.parse_args()
 
+    if args.mode == "group":
+        return bench_group(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # Started without a launcher: start the N ranks ourselves, as fresh child processes, BEFORE this process has
         # touched the GPU (nothing above imports torch or loads the HIP library), relay rank 0's JSON line and exit with

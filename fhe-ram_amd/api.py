@@ -111,6 +111,23 @@ _SYMBOLS = [
     ("fheram_profile_reset", C.c_int, [C.c_void_p]),
     ("fheram_bench_external_product", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("fheram_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    ("fheram_group_create", C.c_int, [C.POINTER(_CParams), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    ("fheram_group_destroy", None, [C.c_void_p]),
+    ("fheram_group_last_error", C.c_char_p, [C.c_void_p]),
+    ("fheram_group_size", C.c_int, [C.c_void_p]),
+    ("fheram_group_ctx", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("fheram_group_keys_load", C.c_int, [C.c_void_p, I64P, C.c_int, C.POINTER(I64P), I64P, C.c_int64, I64P]),
+    ("fheram_group_ram_upload", C.c_int, [C.c_void_p, I64P]),
+    ("fheram_group_ram_download", C.c_int, [C.c_void_p, I64P]),
+    ("fheram_group_ram_tree_download", C.c_int, [C.c_void_p, C.c_int, I64P]),
+    ("fheram_group_ram_state", C.c_int, [C.c_void_p]),
+    ("fheram_group_address_create", C.c_int, [C.c_void_p, C.POINTER(I64P), C.c_int, C.POINTER(C.c_void_p)]),
+    ("fheram_group_address_destroy", None, [C.c_void_p]),
+    ("fheram_group_read", C.c_int, [C.c_void_p, C.c_void_p, I64P]),
+    ("fheram_group_read_prepare_write", C.c_int, [C.c_void_p, C.c_void_p, I64P]),
+    ("fheram_group_write", C.c_int, [C.c_void_p, I64P, C.c_int, C.c_void_p]),
+    ("fheram_group_word_stage", C.c_int, [C.c_void_p, I64P, C.c_int]),
+    ("fheram_group_result_download", C.c_int, [C.c_void_p, I64P]),
     ("fheram_selftest_modarith", C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 6),
     ("fheram_selftest_ntt", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("fheram_selftest_constants", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -350,6 +367,16 @@ class Address:
         s = sum(b.size() for b in self.base2d.v[:i])
         return self.digits[s:s + self.base2d.v[i].size()]
 
+    def _group(self, grp: "GroupRam"):
+        h = self._handles.get(id(grp))
+        if h is None:
+            arr = (I64P * len(self.digits))(*[_p(d) for d in self.digits])
+            out = C.c_void_p()
+            grp._chk(library().fheram_group_address_create(grp._h, arr, len(self.digits), C.byref(out)))
+            h = _GroupAddrHandle(out.value, grp)
+            self._handles[id(grp)] = h
+        return h.h
+
     def _device(self, ram: "Ram"):
         h = self._handles.get(id(ram))
         if h is None:
@@ -360,6 +387,17 @@ class Address:
             h = _AddrHandle(out.value, ram)
             self._handles[id(ram)] = h
         return h.h
+
+
+class _GroupAddrHandle:
+    def __init__(self, h, grp):
+        self.h = h
+        self.ram = grp
+
+    def __del__(self):
+        if self.h and _LIB is not None:
+            _LIB.fheram_group_address_destroy(self.h)
+            self.h = None
 
 
 class FheUintPrepared:
@@ -799,3 +837,103 @@ class Ram:
         cus = C.c_int()
         self._chk(library().fheram_device_info(self._h, buf, 256, C.byref(cus)))
         return {"name": buf.value.decode(), "compute_units": int(cus.value)}
+
+
+class GroupRam:
+    """Ram (ram.rs:25-29) over several GPUs of one node behind ONE handle: the native row-sharded path (fheram_group_*,
+    include/fheram.h) for a single-process host.  Same calls as Ram: read / read_prepare_write / write, one per op
+    (ram.rs:172-176,196-200,226-231).  `devices`: HIP device indices, a power of two of them (the same index may repeat:
+    rehearsal on one GPU)."""
+
+    def __init__(self, params: Optional[Parameters], devices: Sequence[int]):
+        self.params = params or Parameters.new()
+        self.devices = [int(d) for d in devices]
+        self._h = None
+        L = library()
+        out = C.c_void_p()
+        cp = self.params._c()
+        dv = (C.c_int * len(self.devices))(*self.devices)
+        rc = L.fheram_group_create(C.byref(cp), dv, len(self.devices), C.byref(out))
+        if rc != 0:
+            raise FheRamError(rc, L.fheram_group_last_error(None).decode())
+        self._h = out.value
+        self._keys = None
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _LIB is not None:
+            _LIB.fheram_group_destroy(self._h)
+            self._h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise FheRamError(rc, library().fheram_group_last_error(self._h).decode())
+
+    def _use_keys(self, keys: EvaluationKeysPrepared):
+        if self._keys is keys:
+            return
+        L = library()
+        c0 = L.fheram_group_ctx(self._h, 0)
+        atk_len, inv_len = L.fheram_atk_len(c0), L.fheram_evk_inv_len(c0)
+        if keys.atk_glwe is None or any(k.size != atk_len for k in keys.atk_glwe) or keys.atk_ggsw_inv.size != inv_len or keys.tsk_ggsw_inv.size != inv_len:
+            raise FheRamError(1, "evaluation-key layout does not match the group's (parameters.rs:71-93)")
+        arr = (I64P * len(keys.atk_glwe))(*[_p(k) for k in keys.atk_glwe])
+        self._chk(L.fheram_group_keys_load(self._h, _p(keys.gal_els), len(keys.gal_els), arr, _p(keys.atk_ggsw_inv),
+                                           keys.atk_ggsw_inv_p, _p(keys.tsk_ggsw_inv)))
+        self._keys = keys
+
+    def _out(self):
+        return np.zeros((self.params.word_size(), self.params.glwe_len()), dtype=np.int64)
+
+    def load_encrypted(self, rows: np.ndarray):
+        """rows: the whole RAM, [word_size][rows][GLWE] (Ram::encrypt_sk output, ram.rs:129-167)"""
+        p = self.params
+        rows = _i64(rows)
+        if rows.size != p.word_size() * p.rows() * p.glwe_len():
+            raise FheRamError(1, f"invalid data: expected {p.word_size()}x{p.rows()} GLWE rows (ram.rs:144-155)")
+        self._chk(library().fheram_group_ram_upload(self._h, _p(rows)))
+
+    def store_encrypted(self) -> np.ndarray:
+        p = self.params
+        rows = np.zeros((p.word_size(), p.rows(), p.glwe_len()), dtype=np.int64)
+        self._chk(library().fheram_group_ram_download(self._h, _p(rows)))
+        return rows
+
+    def tree(self, level: int = 0) -> np.ndarray:
+        out = self._out()
+        self._chk(library().fheram_group_ram_tree_download(self._h, level, _p(out)))
+        return out
+
+    @property
+    def state(self) -> bool:
+        return bool(library().fheram_group_ram_state(self._h))
+
+    def read(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True):  # ram.rs:172
+        self._use_keys(keys)
+        out = self._out() if download else None
+        self._chk(library().fheram_group_read(self._h, address._group(self), _p(out) if download else None))
+        return out
+
+    def read_prepare_write(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True):  # ram.rs:196
+        self._use_keys(keys)
+        out = self._out() if download else None
+        self._chk(library().fheram_group_read_prepare_write(self._h, address._group(self), _p(out) if download else None))
+        return out
+
+    def write(self, w, address: Address, keys: EvaluationKeysPrepared):  # ram.rs:226
+        self._use_keys(keys)
+        ws = self.params.word_size()
+        if w is None:
+            self._chk(library().fheram_group_write(self._h, None, ws, address._group(self)))
+            return
+        w = _i64(w)
+        n_w = w.shape[0] if w.ndim > 1 else w.size // self.params.glwe_len()
+        self._chk(library().fheram_group_write(self._h, _p(w), n_w, address._group(self)))
+
+    def stage_words(self, w):
+        w = _i64(w)
+        self._chk(library().fheram_group_word_stage(self._h, _p(w), w.shape[0]))
+
+    def result(self):
+        out = self._out()
+        self._chk(library().fheram_group_result_download(self._h, _p(out)))
+        return out

@@ -699,3 +699,4 @@ int fheram_device_info(const fheram_ctx* c, char* name, size_t name_len, int* cu
 
 #include "setup.hpp"
 #include "selftest.hpp"
+#include "group.hpp"

@@ -155,6 +155,39 @@ int fheram_write_begin(fheram_ctx* ctx, const fheram_addr* addr);
 /* Every shard: write_mid_step on its rows with the broadcast ct_lo, then write_last_step (ram.rs:612-630,644-648). */
 int fheram_write_shard(fheram_ctx* ctx, const fheram_addr* addr, const void* ct_lo, int on_device);
 
+/* ---- ONE RAM over the GPUs of a node behind ONE handle (reference API kept: one call per op,
+ * ram.rs:172-176,196-200,226-231).  For a host that is a single process (a Rust `Ram` wrapper): the group owns one
+ * row-shard context per device (rows r = shard (mod n) of every sub-RAM, as above), one host thread per device drives
+ * it, and the two exchange steps — every shard's partial pack to the root for a read, the root's ct_lo to every shard
+ * for a write — are peer-to-peer device copies (xGMI) ordered by events: no host staging, no collective library.
+ * fhe-ram_amd/sharded.py drives the per-shard entry points above from one PROCESS per GPU over RCCL instead; both give
+ * the results of the unsharded path bit for bit.  n_devices must be a power of two <= rows per sub-RAM (1 = plain
+ * context); the same device may be named several times (rehearsal on one GPU).  Group ops are synchronous: they return
+ * when the op is complete on every shard.  One op in flight per group (the reference's `&mut self`). */
+typedef struct fheram_group fheram_group;
+typedef struct fheram_group_addr fheram_group_addr;
+int fheram_group_create(const fheram_params* params, const int* devices, int n_devices, fheram_group** out);   /* Ram::new, ram.rs:59-87 */
+void fheram_group_destroy(fheram_group* grp);
+const char* fheram_group_last_error(const fheram_group* grp);   /* grp == NULL: last fheram_group_create failure */
+int fheram_group_size(const fheram_group* grp);
+/* the shard context behind the group (setup-side calls per shard: fheram_ram_encrypt_sk, fheram_keys_encrypt_sk, ...);
+ * not to be used while a group op is in flight */
+fheram_ctx* fheram_group_ctx(fheram_group* grp, int shard);
+int fheram_group_keys_load(fheram_group* grp, const int64_t* gal_els, int n_gal, const int64_t* const* atk_glwe,
+                           const int64_t* atk_ggsw_inv, int64_t atk_ggsw_inv_p, const int64_t* tsk_ggsw_inv);   /* keys.rs:57-71, replicated */
+/* rows: the WHOLE RAM [word_size][rows][GLWE] (Ram::encrypt_sk output, ram.rs:129-167); scattered / gathered by shard */
+int fheram_group_ram_upload(fheram_group* grp, const int64_t* rows);
+int fheram_group_ram_download(fheram_group* grp, int64_t* rows);
+int fheram_group_ram_tree_download(fheram_group* grp, int level, int64_t* out);
+int fheram_group_ram_state(const fheram_group* grp);
+int fheram_group_address_create(fheram_group* grp, const int64_t* const* ggsw, int n_ggsw, fheram_group_addr** out);   /* address.rs:58,86-109, replicated */
+void fheram_group_address_destroy(fheram_group_addr* addr);
+int fheram_group_read(fheram_group* grp, const fheram_group_addr* addr, int64_t* out);                 /* Ram::read, ram.rs:172-191 */
+int fheram_group_read_prepare_write(fheram_group* grp, const fheram_group_addr* addr, int64_t* out);   /* ram.rs:196-222 */
+int fheram_group_write(fheram_group* grp, const int64_t* w, int n_w, const fheram_group_addr* addr);   /* ram.rs:226-294; w == NULL: staged words */
+int fheram_group_word_stage(fheram_group* grp, const int64_t* w, int n_w);
+int fheram_group_result_download(fheram_group* grp, int64_t* out);
+
 /* ---- Poulpy-level operations reached from the path, exposed for
  * parity tests and micro-benchmarks.  Inputs/outputs are host buffers in the layouts above. */
 

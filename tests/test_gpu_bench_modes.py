@@ -69,3 +69,12 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
     assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)
+
+
+def test_bench_native_group_mode_on_one_gpu():
+    """--mode group: one process drives the sharded RAM through fheram_group_* (here 2 shards on GPU 0)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "group", "--all-ranks-device0",
+                        "--log-max-addr", "13", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = last_json(r.stdout)
+    assert out["mode"] == "group" and out["n_gpus"] == 2 and out["value"] > 0 and "MAX_ADDR=2^14" in out["config"]["workload"]

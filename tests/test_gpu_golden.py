@@ -134,3 +134,44 @@ def test_sharded_flow_matches_committed_digests(po, n_shards, max_addr, device_b
             r.sync()
         shards[0].device_free(parts_ptr)
         shards[0].device_free(ctlo_ptr)
+
+
+@pytest.mark.parametrize("n_devices,key", [(8, 1 << 21), (8, 1 << 18), (2, 1 << 14), (4, "readme_262144")])
+def test_native_group_matches_committed_digests(po, n_devices, key):
+    """fheram_group_* (include/fheram.h): ONE handle, one call per op as the reference's Ram (ram.rs:172-176,196-200,
+    226-231); inside, one host thread per shard context and peer-to-peer device copies for the two exchange steps.  Here
+    every shard sits on GPU 0 (the peer copies are device-to-device copies then); BASELINE.json configs[4] = 2^21 over 8."""
+    pkg = load_package()
+    d, inp = golden_inputs(po, key)
+    ws, max_addr = d["word_size"], d["max_addr"]
+    params = pkg.Parameters(max_addr=max_addr, word_size=ws, **d["params"])
+    grp = pkg.GroupRam(params, [0] * n_devices)
+    keys = pkg.EvaluationKeysPrepared(inp["gal_els"], list(inp["atk_glwe"]), inp["atk_ggsw_inv"], inp["tsk"])
+    addr = pkg.Address(params, list(inp["addr"]))
+    grp.load_encrypted(inp["rows"])
+    out = {"read": sha(grp.read(addr, keys)), "rpw": sha(grp.read_prepare_write(addr, keys)), "rows_after_rpw": sha(grp.store_encrypted()),
+           "tree_after_rpw": sha(grp.tree(0))}
+    assert grp.state
+    with pytest.raises(pkg.FheRamError) as e:        # ram.rs:393-396
+        grp.read(addr, keys)
+    assert e.value.code == 2
+    grp.write(inp["w"], addr, keys)
+    assert not grp.state
+    out["rows_after_write"] = sha(grp.store_encrypted())
+    out["readback"] = sha(grp.read(addr, keys))
+    assert out == d["outputs"]
+    if max_addr > 1 << 18:
+        return
+    # staged words + device-resident result (NULL pointers), as bench.py drives it — against a plain context that has
+    # gone through the same calls (the second round works on rows that carry the first round's noise: no digest for it)
+    ram = pkg.Ram(params, 0)
+    ram.load_encrypted(inp["rows"])
+    ram.read_prepare_write(addr, keys)
+    ram.write(inp["w"], addr, keys)
+    want = ram.read_prepare_write(addr, keys)
+    ram.write(inp["w"], addr, keys)
+    grp.read_prepare_write(addr, keys, download=False)
+    assert np.array_equal(grp.result(), want)
+    grp.stage_words(inp["w"])
+    grp.write(None, addr, keys)
+    assert np.array_equal(grp.store_encrypted(), ram.store_encrypted())
