@@ -29,3 +29,16 @@ def test_soak_single_launch_trace_chain(po):
     import soak_tail_gpu
     rounds, st = soak_tail_gpu.main(seconds=15, seed=20261005)
     assert rounds >= 5 and st["launches"] >= 3 * rounds and st["fallbacks"] <= st["launches"]
+
+
+@pytest.mark.parametrize("params", ["source", "readme"])
+def test_noise_growth_over_consecutive_write_cycles(po, params):
+    """BASELINE.json configs[3] 'noise growth checked': a bounded run of tests/noise_growth_gpu.py (the long one is
+    profiles/r03_noise_growth*.json): 400 read_prepare_write + write cycles at 2^14; every sampled read decrypts to the
+    plaintext model with noise below the reference's bound, and the fitted growth leaves room for the README's 40
+    million cycles."""
+    import noise_growth_gpu
+    out = noise_growth_gpu.run(cycles=400, sample_every=50, log_max_addr=14, params=params, pool=16)
+    assert out["worst_noise_bits"] < out["noise_bound_bits"]
+    assert out["last"]["cycle"] == 400 and len(out["trajectory"]) == 9
+    print({k: out[k] for k in ("worst_noise_bits", "noise_bound_bits", "cycles_per_s", "fit_variance")})
