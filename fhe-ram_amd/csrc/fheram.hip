@@ -118,6 +118,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->tail_test = (tl && tl[0] == '2') ? 1 : ((tl && tl[0] == '3') ? 2 : 0);
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
+        const char* cy = getenv("FHERAM_CHAIN_Y");
+        c->chain_y = (cy && cy[0] == '0') ? 0 : 1;
         const char* gr = getenv("FHERAM_GRAPH");
         c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
         // a captured launch sequence must be a pure function of (context, address, op): under replay the write always

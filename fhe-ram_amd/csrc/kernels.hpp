@@ -69,6 +69,53 @@ struct GlweRef {   // p + y*sy + x*sx  (int32 elements)
 __device__ __forceinline__ int32_t* at(const GlweRef& r) { return r.p + (long)blockIdx.y * r.sy + (long)blockIdx.x * r.sx; }
 __device__ __forceinline__ long glwe_off(int limb, int col) { return (long)(limb * 2 + col) * N; }
 
+// Global accesses as (wave-uniform 64-bit base in scalar registers) + (32-bit lane offset): `global_load_dword v, v_off,
+// s[base]`.  The limb / column / coefficient-block part of an address is the same for every lane; left to itself the
+// compiler adds it to the lane's 64-bit address with two VALU instructions per access (~100 per key-switch input, ~130 per
+// output).  The empty asm pins the base to SGPRs and keeps the zero extension of the offset next to the access, which is
+// what instruction selection needs to pick the scalar-base form.  `base` MUST be wave uniform.
+#ifndef FK_SADDR
+#define FK_SADDR 1
+#endif
+typedef const __attribute__((address_space(1))) char* gbytes_t;
+typedef __attribute__((address_space(1))) char* gbytes_w_t;
+__device__ __forceinline__ int gload_i32(const int32_t* base, unsigned byte_off) {
+#if FK_SADDR
+    gbytes_t b = (gbytes_t)reinterpret_cast<const char*>(base);
+    asm("" : "+s"(b));
+    return *(const __attribute__((address_space(1))) int*)(b + byte_off);
+#else
+    return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off);
+#endif
+}
+__device__ __forceinline__ double gload_f64(const double* base, unsigned byte_off) {
+#if FK_SADDR
+    gbytes_t b = (gbytes_t)reinterpret_cast<const char*>(base);
+    asm("" : "+s"(b));
+    return *(const __attribute__((address_space(1))) double*)(b + byte_off);
+#else
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+#endif
+}
+__device__ __forceinline__ void gstore_f64(double* base, unsigned byte_off, double v) {
+#if FK_SADDR
+    gbytes_w_t b = (gbytes_w_t)reinterpret_cast<char*>(base);
+    asm("" : "+s"(b));
+    *(__attribute__((address_space(1))) double*)(b + byte_off) = v;
+#else
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + byte_off) = v;
+#endif
+}
+__device__ __forceinline__ void gstore_i32(int32_t* base, unsigned byte_off, int v) {
+#if FK_SADDR
+    gbytes_w_t b = (gbytes_w_t)reinterpret_cast<char*>(base);
+    asm("" : "+s"(b));
+    *(__attribute__((address_space(1))) int*)(b + byte_off) = v;
+#else
+    *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(base) + byte_off) = v;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 // k_prepare: forward transform of `npoly` small polynomials into prepared form.
 // ginv != 0: the polynomial is first mapped through phi_g (g = ginv^-1 mod 2N), i.e. the prepared
@@ -120,9 +167,30 @@ __device__ __forceinline__ void mac_poly(double (&acc)[E], const double (&x)[E],
 // Prepared-operand registers of one polynomial (E/2 16-byte words per thread).
 struct OpRegs { double2 v[E / 2]; };
 __device__ __forceinline__ void load_ops(OpRegs& o, const double* __restrict__ g, int tid) {
+#if FK_SADDR
+    // Every operand polynomial of a launch is addressed as (wave-uniform base) + (lane offset): the base — key / GGSW
+    // pointer, limb, column, kk * 8 KiB — lives in scalar registers and is advanced by scalar adds, the lane offset is ONE
+    // 32-bit register (tid * 16) for all loads: `global_load_dwordx4 v, v_off, s[base]`.  Left to itself the compiler folds
+    // the kk * 8 KiB into the vector address and spends a 64-bit VALU add per load (24 VALU instructions per output limb).
+    // The empty asm makes the base opaque (and pins it to SGPRs), so the constant cannot migrate.
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) char* gbytes;       // global address space, spelled out: the asm below
+    typedef const __attribute__((address_space(1))) d2v* gwords;        // would otherwise leave a generic (flat) pointer
+    unsigned off = (unsigned)tid * 16u;
+    asm("" : "+v"(off));   // opaque per call: the zero extension of the offset must stay next to the loads (not hoisted out of the limb loop) for the scalar-base form to be selected
+#pragma unroll
+    for (int kk = 0; kk < E / 2; kk++) {
+        gbytes base = (gbytes)reinterpret_cast<const char*>(g) + (size_t)kk * T * 16;
+        asm("" : "+s"(base));
+        const d2v w = *(gwords)(base + off);
+        o.v[kk].x = w.x;
+        o.v[kk].y = w.y;
+    }
+#else
     const double2* gp = reinterpret_cast<const double2*>(g);
 #pragma unroll
     for (int kk = 0; kk < E / 2; kk++) o.v[kk] = gp[kk * T + tid];
+#endif
 }
 __device__ __forceinline__ void mac_regs(double (&acc)[E], const double (&x)[E], const OpRegs& o) {
 #pragma unroll
@@ -238,7 +306,7 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
 #pragma unroll
         for (int r = 0; r < SA; r++)
 #pragma unroll
-            for (int k = 0; k < E; k++) xi[r][k] = ap[glwe_off(r, 0) + tid + T * k];
+            for (int k = 0; k < E; k++) xi[r][k] = gload_i32(ap + glwe_off(r, 0), (unsigned)(tid + T * k) * 4u);
         if (load_tw) twiddles_commit(twr, tw, tid);
 #pragma unroll
         for (int r = 0; r < SA; r++)
@@ -247,7 +315,7 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
 #pragma unroll
         for (int r = 0; r < SA; r++)
 #pragma unroll
-            for (int k = 0; k < E; k++) xi[r][k] = ap[glwe_off(r, 1) + tid + T * k];
+            for (int k = 0; k < E; k++) xi[r][k] = gload_i32(ap + glwe_off(r, 1), (unsigned)(tid + T * k) * 4u);
         fwd_all<SA>(x0, tw, data, tid);
 #pragma unroll
         for (int r = 0; r < SA; r++)
@@ -292,7 +360,7 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
                 const double v = v_[k] + carry[k];
                 const double cy = carry_of(v);
                 carry[k] = cy;
-                if (j < SA) rp[glwe_off(j, co) + tid + T * k] = (int)digit_of(v, cy);
+                if (j < SA) gstore_i32(rp + glwe_off(j, co), (unsigned)(tid + T * k) * 4u, (int)digit_of(v, cy));
             }
         };
         constexpr int REM = SG % BI;   // limbs left over for a final narrower batch
@@ -441,8 +509,8 @@ __device__ __forceinline__ void load_raw(const KsArgs& ka, const int32_t* ap, co
     if constexpr (MODE == KS_PAIR) rot_src(i, -ka.t, src, r.neg);
 #pragma unroll
     for (int j = 0; j < SX; j++) {
-        r.a[j] = ap[glwe_off(j, col) + src];
-        if constexpr (MODE == KS_PAIR) r.b[j] = bp[glwe_off(j, col) + i];
+        r.a[j] = gload_i32(ap + glwe_off(j, col), (unsigned)src * 4u);
+        if constexpr (MODE == KS_PAIR) r.b[j] = gload_i32(bp + glwe_off(j, col), (unsigned)i * 4u);
     }
 }
 template <int MODE, int SX>
@@ -741,9 +809,9 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
                         int dst = i + ka.t;
                         const bool ng = dst >= N;
                         if (ng) dst -= N;
-                        op[glwe_off(j, co) + dst] = cneg((int)digit_of(v2, cy2), ng);
+                        gstore_i32(op + glwe_off(j, co), (unsigned)dst * 4u, cneg((int)digit_of(v2, cy2), ng));
                     } else {
-                        op[glwe_off(j, co) + i] = (int)d;
+                        gstore_i32(op + glwe_off(j, co), (unsigned)i * 4u, (int)d);
                     }
                 }
             }
@@ -803,6 +871,162 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     ks_run<MODE, SX, SK, SO, NCO, STAGE>(ka, lds, true, (int)threadIdx.x);
 }
+// ---------------------------------------------------------------------------------------
+// One fused trace step (a <- rsh1(a); a <- a + phi_g(KS(a)): GLWE::trace, ram.rs:457,540,572,616,621, and the packer
+// levels in which a leaf is alone, ram.rs:435,514) for the steps INSIDE a chain launch, where producer and consumer of an
+// intermediate ciphertext are the same workgroup and its form is ours to choose.
+//
+// vec_znx_rsh(1) has a closed form: with A = a_0*2^34 + a_1*2^17 + a_2 the integer the three limbs of a coefficient
+// stand for, rsh1(a) is the unique centred base-2^17 digit vector of Y = ceil(A / 2) (each odd limb sends -2^16 to the
+// next limb and rounds itself up, the last one only rounds up: oracle/znx.hpp rsh_inplace; checked against it digit for
+// digit incl. un-normalised +2^16 limbs, tests/test_oracle.py::test_rsh1_closed_form).  |A| < 2^51, so A and Y are exact
+// doubles and every operation below (scaling by powers of two, +0.5, floor, fma with an exact result) is exact.
+//
+// So the chain hands Y over — ONE double per coefficient and column, [col][N] in the ciphertext's slot — instead of the
+// normalised limbs: the producer folds its output digits into A with one fma each (instead of a conversion and a store
+// per limb) and stores floor(A/2 + 1/2); the consumer takes the digits of Y where it needs them, three FP64 instructions
+// per digit, as doubles (no integer pre-step, no packing, no int -> double conversions, a third of the loads, stores and
+// staging traffic).  Digits are the same integers either way: results are bit-identical to the limb form.
+//   IN_Y  : the input is in that form (else: an int32 GLWE, read rotated by X^-rho, write path ram.rs:621,629)
+//   OUT_Y : the output is written in that form (else: an int32 GLWE)
+// ---------------------------------------------------------------------------------------
+constexpr double TWO_2B = 17179869184.0;   // 2^34
+// c = q * 2^17 + d with d in [-2^16, 2^16): returns d, leaves q in c
+__device__ __forceinline__ double take_digit(double& c) {
+    const double q = carry_of(c);
+    const double d = digit_of(c, q);
+    c = q;
+    return d;
+}
+template <int SK, bool IN_Y, bool OUT_Y>
+__device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool load_tw, const int tid) {
+    constexpr int SX = 3, SO = 3;
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    TwRegs twr;
+    if (load_tw) twiddles_issue(twr, ka.tw, tid);
+    const int32_t* ap = at(ka.a);
+    int32_t* op = at(ka.out);
+    double* ystage = data;                    // exchange buffer 0, before any transform: Y of the mask column, natural order
+    double* bstage = data + 2 * LDS_DATA;     // third exchange buffer: the double-buffered inverse transforms leave it alone
+    static_assert((size_t)N * sizeof(double) <= (size_t)LDS_DATA * sizeof(double), "a staged column fits one exchange buffer");
+    const int sidx0 = (tid * ka.ginv) & (2 * N - 1);      // phi_g: destination i' = tid + T*k takes +-source i = i' * ginv mod 2N
+    const int sstep = (T * ka.ginv) & (2 * N - 1);
+
+    double y0[E], y1[E];                      // Y of column 0 (body) / column 1 (mask) at the natural coefficients tid + T*k
+    if constexpr (IN_Y) {
+        const double* yp = reinterpret_cast<const double*>(ap);
+#pragma unroll
+        for (int k = 0; k < E; k++) y1[k] = gload_f64(yp + N, (unsigned)(tid + T * k) * 8u);
+#pragma unroll
+        for (int k = 0; k < E; k++) y0[k] = gload_f64(yp, (unsigned)(tid + T * k) * 8u);
+    } else {
+        RawX<KS_TRACE, SX> rm[E], rb[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, 1, tid + T * k, rm[k]);
+#pragma unroll
+        for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, 0, tid + T * k, rb[k]);
+        __builtin_amdgcn_sched_barrier(0);
+        auto y_of = [](const RawX<KS_TRACE, SX>& r) {
+            double a = __builtin_fma(__builtin_fma((double)r.a[0], TWO_B, (double)r.a[1]), TWO_B, (double)r.a[2]);
+            a = r.neg ? -a : a;                                        // the rotation's sign comes before the shift
+            return __builtin_floor(__builtin_fma(a, 0.5, 0.5));       // ceil(A / 2)
+        };
+#pragma unroll
+        for (int k = 0; k < E; k++) { y1[k] = y_of(rm[k]); y0[k] = y_of(rb[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < E; k++) ystage[tid + T * k] = y1[k];
+    if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();   // its barrier also publishes the staged column
+
+    // Phase 1: the digits of the mask column seen through phi_g, transformed
+    double xh[SX][E];
+    {
+        int sidx = sidx0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const bool ng = sidx >= N;
+            double c = ystage[sidx & (N - 1)];
+            const double d2 = take_digit(c);
+            const double d1 = take_digit(c);
+            // |Y| < 2^49 + 2^33: the second quotient is below 2^16 in magnitude and IS the top digit (no wrap to take care of)
+            xh[2][k] = ng ? -d2 : d2;
+            xh[1][k] = ng ? -d1 : d1;
+            xh[0][k] = ng ? -c : c;
+            sidx = (sidx + sstep) & (2 * N - 1);
+        }
+    }
+    fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before buffer 0 is overwritten
+
+    int it = 0;
+#pragma unroll 1
+    for (int co = 0; co < 2; co++) {
+        double cq[E];                  // running quotient of this column's Y: the post-step takes its digits from the least significant one upwards, as the limbs are produced
+#pragma unroll
+        for (int k = 0; k < E; k++) cq[k] = (co == 0) ? y0[k] : y1[k];
+        if (co == 0) {                 // the body column, staged for the gathers of add_body
+            lds_barrier();             // slower waves may still be inside the wave-local exchanges of the forward transforms
+#pragma unroll
+            for (int k = 0; k < E; k++) bstage[tid + T * k] = y0[k];
+            // published by the barriers of the first inverse transform, which precede every gather
+        }
+        double carry[E], od[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) { carry[k] = 0.0; od[k] = 0.0; }
+        OpRegs g[SX];
+        auto fetch = [&](int j) {
+#pragma unroll
+            for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
+        };
+        fetch(SK - 1);
+#pragma unroll 1
+        for (int j = SK - 1; j >= 0; j--) {
+            double acc[1][E];
+#pragma unroll
+            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+#pragma unroll
+            for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
+            __builtin_amdgcn_sched_barrier(0);
+            ntt_inv<1, false, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);   // 3 MAC terms: no initial reduction; double-buffered exchanges
+            if (j >= 1) fetch(j - 1);                                                // next limb's operands: their latency overlaps the post-step
+            if (co == 0 && j < SX) {   // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
+                int sidx = sidx0;
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    double c = bstage[sidx & (N - 1)];
+                    double d = take_digit(c);
+                    if (j <= 1) d = take_digit(c);
+                    if (j == 0) d = c;
+                    acc[0][k] += (sidx >= N) ? -d : d;
+                    sidx = (sidx + sstep) & (2 * N - 1);
+                }
+            }
+            const double scale = (j == 2) ? 1.0 : ((j == 1) ? TWO_B : TWO_2B);
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                double v = acc[0][k];
+                if (j < SX) {          // a + phi(KS(a)): limb j of rsh1(a) = digit j of Y
+                    const double xl = (j > 0) ? take_digit(cq[k]) : cq[k];
+                    v += xl;
+                }
+                v += carry[k];
+                const double cy = carry_of(v);
+                carry[k] = cy;
+                if (j < SO) {
+                    const double d = digit_of(v, cy);
+                    if constexpr (OUT_Y) od[k] = __builtin_fma(d, scale, od[k]);
+                    else gstore_i32(op + glwe_off(j, co), (unsigned)(tid + T * k) * 4u, (int)d);
+                }
+            }
+        }
+        if constexpr (OUT_Y) {
+            double* yo = reinterpret_cast<double*>(op) + (long)co * N;
+#pragma unroll
+            for (int k = 0; k < E; k++) gstore_f64(yo, (unsigned)(tid + T * k) * 8u, __builtin_floor(__builtin_fma(od[k], 0.5, 0.5)));
+        }
+    }
+}
+
 // GLWE::trace(start, start + n) (ram.rs:457,540,572,616,621 and the packer levels in which every
 // leaf is alone) as ONE launch: n trace steps on the same ciphertext, one workgroup per ciphertext, ping-pong
 // between the workgroup's own slots of two buffers (see k_ext_product_chain).  Only the first step may read its
@@ -816,6 +1040,7 @@ struct KsChainArgs {
     const unsigned* pred = nullptr;  // fallback launch behind k_trace_tail: runs only if *pred == pred_seq (that launch gave up)
     unsigned pred_seq = 0;
     unsigned* host_count = nullptr;  // pinned host word that mirrors the number of fallbacks taken (read by the host without a sync)
+    int yform = 0;                   // 1: the intermediate ciphertexts of the chain are handed over as Y = ceil(A/2) (ks_trace_y); needs n >= 2
 };
 template <int SX, int SK, int SO>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) {
@@ -837,7 +1062,17 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) 
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
         __builtin_assume(tid >= 0 && tid < T);
-        ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
+        if constexpr (SX == 3 && SO == 3) {
+            if (ca.yform) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y)
+                if (i == 0) ks_trace_y<SK, false, true>(ka, lds, true, tid);
+                else if (i + 1 < ca.n) ks_trace_y<SK, true, true>(ka, lds, false, tid);
+                else ks_trace_y<SK, true, false>(ka, lds, false, tid);
+            } else {
+                ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
+            }
+        } else {
+            ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
+        }
         __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
         ka.a = ka.out;
         ka.rot_mul = 0;

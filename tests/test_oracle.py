@@ -271,3 +271,42 @@ def test_committed_digests_cover_the_full_sizes():
     for size in ("4096", "16384", "262144", "2097152", "readme_16384", "readme_262144"):      # BASELINE.json configs[0], source default, configs[2..3], configs[4]; README.md:17-34 block
         assert {"read", "rpw", "rows_after_rpw", "rows_after_write", "readback"} <= set(d[size]["outputs"])
         assert d[size]["max_big_log2"] < 47
+
+
+def test_rsh1_closed_form(po):
+    """vec_znx_rsh(1) (oracle/znx.hpp rsh_inplace; GLWE::trace / GLWEPacker, ram.rs:435,457) equals the centred base-2^17
+    digits of ceil(A / 2), A = a_0*2^34 + a_1*2^17 + a_2 — the form the HIP trace chains hand their intermediate
+    ciphertexts over in (csrc/kernels.hpp ks_trace_y).  Every floating-point operation of that form is exact (powers of
+    two, +0.5, floor, differences of exact values), so numpy float64 reproduces the device arithmetic; compared digit for
+    digit with the oracle on random limbs and on the extremes (+-2^16, the un-normalised +2^16 a rotation's negation
+    produces, odd / even tails)."""
+    o = po.Oracle(po.OParams(log_n=4, max_addr=16, decomp_n=[2, 2]))
+    n, B = 16, 2.0 ** 17
+    rng = np.random.default_rng(1)
+
+    def closed_form(g):
+        x = g.reshape(3, 2, n).astype(np.float64)
+        A = (x[0] * B + x[1]) * B + x[2]
+        assert np.all(np.abs(A) < 2.0 ** 51)
+        Y = np.floor(A * 0.5 + 0.5)
+        q1 = np.floor(Y / B + 0.5)
+        q2 = np.floor(q1 / B + 0.5)
+        assert np.all(np.abs(q2) < 2 ** 16)                 # the second quotient IS the top digit: no wrap (ks_trace_y relies on it)
+        return np.stack([q2, q1 - q2 * B, Y - q1 * B]).astype(np.int64).reshape(-1)
+
+    edge = np.array([-(1 << 16), (1 << 16) - 1, 1 << 16, 0, 1, -1, 2, -2, 65535, -65535])
+    for it in range(1500):
+        mode = it % 5
+        if mode == 0:
+            g = rng.integers(-(1 << 16), 1 << 16, size=3 * 2 * n, dtype=np.int64)
+        elif mode == 1:
+            g = rng.choice(edge, size=3 * 2 * n).astype(np.int64)
+        elif mode == 2:
+            g = rng.integers(-(1 << 16), (1 << 16) + 1, size=3 * 2 * n, dtype=np.int64)
+            g[:2 * n] = rng.choice(np.array([1 << 16, -(1 << 16)]), size=2 * n)
+        elif mode == 3:
+            g = rng.integers(-3, 4, size=3 * 2 * n, dtype=np.int64)
+        else:
+            g = rng.integers(-(1 << 16), (1 << 16) + 1, size=3 * 2 * n, dtype=np.int64)
+            g[4 * n:] = rng.choice(edge, size=2 * n)
+        assert np.array_equal(closed_form(g), o.glwe_rsh(1, g)), (it, mode)
