@@ -72,6 +72,7 @@ _SYMBOLS = [
     ("fheram_write", C.c_int, [C.c_void_p, I64P, C.c_int, C.c_void_p]),
     ("fheram_word_stage", C.c_int, [C.c_void_p, I64P, C.c_int]),
     ("fheram_result_download", C.c_int, [C.c_void_p, I64P]),
+    ("fheram_result_map", C.c_int, [C.c_void_p, C.POINTER(I64P)]),
     ("fheram_sync", C.c_int, [C.c_void_p]),
     ("fheram_ctx_create_sharded", C.c_int, [C.POINTER(_CParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("fheram_shard_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
@@ -655,17 +656,20 @@ class Ram:
         return bool(library().fheram_ram_state(self._h))
 
     # -- the path
-    def read(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True):  # ram.rs:172
+    def read(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True, out=None):  # ram.rs:172
+        """out: an int64 array [word_size][GLWE] to receive the result (a host that reads in a loop reuses one)"""
         self._use_keys(keys)
-        out = self._out() if download else None
+        if download and out is None:
+            out = self._out()
         self._chk(library().fheram_read(self._h, address._device(self), _p(out) if download else None))
-        return out
+        return out if download else None
 
-    def read_prepare_write(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True):  # ram.rs:196
+    def read_prepare_write(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True, out=None):  # ram.rs:196
         self._use_keys(keys)
-        out = self._out() if download else None
+        if download and out is None:
+            out = self._out()
         self._chk(library().fheram_read_prepare_write(self._h, address._device(self), _p(out) if download else None))
-        return out
+        return out if download else None
 
     def write(self, w, address: Address, keys: EvaluationKeysPrepared):  # ram.rs:226
         self._use_keys(keys)
@@ -746,6 +750,14 @@ class Ram:
         out = self._out()
         self._chk(library().fheram_result_download(self._h, _p(out)))
         return out
+
+    def result_view(self) -> np.ndarray:
+        """the result of the last read in place (the context's pinned host buffer, fheram_result_map): valid until the
+        next operation on this Ram — copy it if it has to live longer"""
+        ptr = I64P()
+        self._chk(library().fheram_result_map(self._h, C.byref(ptr)))
+        p = self.params
+        return np.ctypeslib.as_array(ptr, shape=(p.word_size(), p.glwe_len()))
 
     def sync(self):
         self._chk(library().fheram_sync(self._h))

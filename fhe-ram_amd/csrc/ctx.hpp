@@ -155,6 +155,15 @@ struct fheram_ctx {
     int32_t* d_trhi = nullptr;     // arena that holds trace(ct_hi) of the local rows during a write (A or C)
     int32_t* h_pin[2] = {nullptr, nullptr};   // pinned host staging (hand-over of int64 host buffers)
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
+    // the two hand-overs ON the path (result of a read out, words of a write in) have staging of their own:
+    //  h_res: pinned, device-visible; an export kernel widens the result into it as int64 in the ABI's layout (no DMA
+    //         engine round trip, no host-side widening: the host copies it out, or reads it in place, fheram_result_map)
+    //  h_w  : pinned; the host narrows the words into it and an asynchronous copy takes them to d_w — the call does not wait
+    int64_t* h_res = nullptr;
+    int64_t* d_h_res = nullptr;               // device address of h_res
+    int32_t* h_w = nullptr;
+    hipEvent_t ev_w = nullptr;
+    bool w_busy = false;
     // profiling
     bool profile = false;
     std::map<std::string, ProfCls> prof;

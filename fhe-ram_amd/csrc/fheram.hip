@@ -199,6 +199,10 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipMemset(c->d_tail_sync, 0, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     CCHK(hipHostMalloc((void**)&c->h_tail_fb, 64, hipHostMallocDefault));
     *c->h_tail_fb = 0;
+    CCHK(hipHostMalloc((void**)&c->h_res, (size_t)c->ws * G * sizeof(int64_t), hipHostMallocMapped));
+    CCHK(hipHostGetDevicePointer((void**)&c->d_h_res, c->h_res, 0));
+    CCHK(hipHostMalloc((void**)&c->h_w, (size_t)c->ws * G * sizeof(int32_t), hipHostMallocDefault));
+    CCHK(hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming));
 #undef CCHK
     *out = c;
     return FHERAM_OK;
@@ -224,6 +228,9 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
+    if (c->h_res) hipHostFree(c->h_res);
+    if (c->h_w) hipHostFree(c->h_w);
+    if (c->ev_w) hipEventDestroy(c->ev_w);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -323,10 +330,24 @@ void fheram_address_destroy(fheram_addr* a) {
     delete a;
 }
 
-int fheram_result_download(fheram_ctx* c, int64_t* out) {
+int fheram_result_map(fheram_ctx* c, const int64_t** out) {
     if (!c || !out) return FHERAM_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    return download_i64(c, out, c->d_last_res ? c->d_last_res : c->d_res, (size_t)c->ws * fheram_ctx::GLWE);
+    const int n4 = (int)((size_t)c->ws * fheram_ctx::GLWE / 4);
+    hipLaunchKernelGGL(k_export_i64, dim3((n4 + 255) / 256), dim3(256), 0, c->stream, c->d_last_res ? c->d_last_res : c->d_res,
+                       reinterpret_cast<long long*>(c->d_h_res), n4);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    *out = c->h_res;
+    return FHERAM_OK;
+}
+int fheram_result_download(fheram_ctx* c, int64_t* out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    const int64_t* src = nullptr;
+    const int rc = fheram_result_map(c, &src);
+    if (rc != FHERAM_OK) return rc;
+    std::memcpy(out, src, (size_t)c->ws * fheram_ctx::GLWE * sizeof(int64_t));
+    return FHERAM_OK;
 }
 int fheram_sync(fheram_ctx* c) {
     if (!c) return FHERAM_ERR_INVALID_ARG;
@@ -363,9 +384,16 @@ int fheram_word_stage(fheram_ctx* c, const int64_t* w, int n_w) {
     if (!c || !w) return FHERAM_ERR_INVALID_ARG;
     if (n_w != c->ws) return fail(c, FHERAM_ERR_INVALID_ARG, "w.len() != subrams.len() (ram.rs:243)");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = upload_i64(c, c->d_w, w, (size_t)c->ws * fheram_ctx::GLWE);
-    if (rc == FHERAM_OK) c->words_staged = true;
-    return rc;
+    // narrowed into a pinned buffer of its own and copied asynchronously: the call does not wait for the copy (the kernels
+    // that read d_w are ordered behind it on the stream; the buffer is reused only after its event)
+    if (c->w_busy) { HIPCHK(c, hipEventSynchronize(c->ev_w)); c->w_busy = false; }
+    const size_t n = (size_t)c->ws * fheram_ctx::GLWE;
+    if (!narrow(w, c->h_w, n)) return fail(c, FHERAM_ERR_RANGE, "limb out of the normalised range [-2^16, 2^16]");
+    HIPCHK(c, hipMemcpyAsync(c->d_w, c->h_w, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_w, c->stream));
+    c->w_busy = true;
+    c->words_staged = true;
+    return FHERAM_OK;
 }
 // Ram::write, ram.rs:226-294
 int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* addr) {
@@ -374,9 +402,12 @@ int fheram_write(fheram_ctx* c, const int64_t* w, int n_w, const fheram_addr* ad
     if (n_w != c->ws) return fail(c, FHERAM_ERR_INVALID_ARG, "w.len() != subrams.len() (ram.rs:243)");
     if (!c->state) return fail(c, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
     HIPCHK(c, hipSetDevice(c->device));
-    if (w) { rc = fheram_word_stage(c, w, n_w); if (rc != FHERAM_OK) return rc; }
-    else if (!c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
     if (c->n_shards != 1) return fail(c, FHERAM_ERR_INVALID_ARG, "row-sharded context: use fheram_write_root / fheram_write_shard");
+    if (!w && !c->words_staged) return fail(c, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
+    // the part of a write that needs no words (trace(ct_hi) of every row, inverse of coordinate 0) is enqueued BEFORE the host
+    // narrows the words: the GPU works while the host converts
+    if (w && !c->side_begun && !(c->use_graph && !c->profile)) write_side_begin(c, addr);
+    if (w) { rc = fheram_word_stage(c, w, n_w); if (rc != FHERAM_OK) { write_side_abort(c); return rc; } }
     rc = run_op(c, addr, 2, [&] {
         if (!c->side_begun) write_side_begin(c, addr);   // (fheram_write_begin may have started it)
         int r2 = write_top(c, addr);

@@ -1631,6 +1631,16 @@ __global__ __launch_bounds__(256) void k_sub_add_norm(GlweRef a, GlweRef b, Glwe
         for (int j = 0; j < S; j++) op[glwe_off(j, col) + i] = (int)out_l[j];
     }
 }
+// int32 device limbs -> int64 host layout, written straight into pinned host memory (the result of a read)
+__global__ __launch_bounds__(256) void k_export_i64(const int32_t* __restrict__ src, long long* __restrict__ dst, int n4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int4 v = reinterpret_cast<const int4*>(src)[i];
+    longlong2 a, b;
+    a.x = v.x; a.y = v.y; b.x = v.z; b.y = v.w;
+    reinterpret_cast<longlong2*>(dst)[2 * i] = a;
+    reinterpret_cast<longlong2*>(dst)[2 * i + 1] = b;
+}
 // out = a   (glwe_copy, ram.rs:526,535,537)
 template <int S>
 __global__ __launch_bounds__(256) void k_copy(GlweRef a, GlweRef out) {

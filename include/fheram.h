@@ -107,6 +107,10 @@ int fheram_read_prepare_write(fheram_ctx* ctx, const fheram_addr* addr, int64_t*
 int fheram_write(fheram_ctx* ctx, const int64_t* w, int n_w, const fheram_addr* addr);
 int fheram_word_stage(fheram_ctx* ctx, const int64_t* w, int n_w);
 int fheram_result_download(fheram_ctx* ctx, int64_t* out);
+/* The result of the last read / read_prepare_write in place: [word_size][GLWE] int64 in the context's pinned host buffer
+ * (the device widens it straight into host memory; no copy on the host).  Valid until the next operation on ctx.  A Rust
+ * shim builds its Vec<GLWE<Vec<u8>>> (ram.rs:176) from it with one copy instead of two. */
+int fheram_result_map(fheram_ctx* ctx, const int64_t** out);
 /* Block until every queued operation of ctx has finished. */
 int fheram_sync(fheram_ctx* ctx);
 
