@@ -111,6 +111,7 @@ _SYMBOLS = [
     ("fheram_tail_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fheram_profile_reset", C.c_int, [C.c_void_p]),
     ("fheram_bench_external_product", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    ("fheram_bench_chain", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("fheram_device_info", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     ("fheram_group_create", C.c_int, [C.POINTER(_CParams), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     ("fheram_group_destroy", None, [C.c_void_p]),
@@ -148,7 +149,10 @@ def library():
             raise FheRamError(7, f"HIP extension missing: {path} not built (run __graft_entry__.build()); "
                                  "there is no CPU fallback")
         L = C.CDLL(path)
+        lenient = bool(os.environ.get("FHERAM_LIB"))   # an experimental build named by FHERAM_LIB (A/B runs) may predate newer entry points
         for name, res, args in _SYMBOLS:
+            if lenient and not hasattr(L, name):
+                continue
             f = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             f.restype = res
             f.argtypes = args
@@ -843,6 +847,12 @@ class Ram:
         dp = lambda v: v.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
         self._chk(library().fheram_selftest_ntt(self._h, direction, x.shape[0], dp(x), dp(out)))
         return out
+
+    def bench_chain(self, kind: int, batch: int, n: int, iters: int) -> float:
+        """ms for `iters` back-to-back runs of a dependent chain on `batch` ciphertexts: kind 0 = n trace steps, 1 = n external products"""
+        ms = C.c_float()
+        self._chk(library().fheram_bench_chain(self._h, kind, batch, n, iters, C.byref(ms)))
+        return float(ms.value)
 
     def device_info(self):
         buf = C.create_string_buffer(256)

@@ -139,6 +139,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product_fine<4, 5>));
     LDSATTR((&k_ext_product_chain<3, 4>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
+    LDSATTR((&k_keyswitch_chain<3, 4, 3, true>));
+    LDSATTR((&k_keyswitch_chain<3, 5, 3, true>));
     LDSATTR((&k_trace_tail<3, 4, 3>));
 #define LDSATTR_KS4(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
 #define LDSATTR_KS(M, SX, SK, SO) LDSATTR_KS4(M, SX, SK, SO); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>))
@@ -713,6 +715,41 @@ int fheram_bench_external_product(fheram_ctx* c, int batch, int iters, float* to
     for (int i = 0; i < 3; i++) { launch_ep(c, ra, rb, c->d_prep, batch, 1); launch_ep(c, rb, ra, c->d_prep, batch, 1); }   // warm-up
     HIPCHK(c, hipEventRecord(c->t0, c->stream));
     for (int i = 0; i < iters; i++) launch_ep(c, (i & 1) ? rb : ra, (i & 1) ? ra : rb, c->d_prep, batch, 1);
+    HIPCHK(c, hipEventRecord(c->t1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->t1));
+    HIPCHK(c, hipEventElapsedTime(total_ms, c->t0, c->t1));
+    HIPCHK(c, hipGetLastError());
+    return FHERAM_OK;
+}
+int fheram_bench_chain(fheram_ctx* c, int kind, int batch, int n, int iters, float* total_ms) {
+    if (!c || !total_ms || batch <= 0 || iters <= 0 || n < 1 || n > CHAIN_MAX || kind < 0 || kind > 1) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t G = fheram_ctx::GLWE;
+    DevBuf da, db, dc, dg;
+    HIPCHK(c, hipMalloc(&da.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&db.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&dc.p, (size_t)batch * G * 4));
+    HIPCHK(c, hipMalloc(&dg.p, (size_t)n * fheram_ctx::GGSW * 4));
+    {   // synthetic normalised limbs; the trace keys of the context are used as they are (synthetic ones if none were loaded)
+        std::vector<int32_t> h(std::max((size_t)batch * G, (size_t)n * fheram_ctx::GGSW));
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (int32_t)(x & 0x1FFFF) - 65536; }
+        HIPCHK(c, hipMemcpy(da.p, h.data(), (size_t)batch * G * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(dg.p, h.data(), (size_t)n * fheram_ctx::GGSW * 4, hipMemcpyHostToDevice));
+        if (kind == 0 && !c->keys_loaded)
+            for (int i = 0; i < LOGN; i++) { c->cur = c->stream; launch_prepare(c, dg.p, c->d_atk + (size_t)i * c->atk, (int)(c->atk / N), c->gal[i]); }
+    }
+    c->cur = c->stream;
+    if (kind == 1) launch_prepare(c, dg.p, c->d_prep, n * (int)(fheram_ctx::GGSW / N));
+    GlweRef ra = ref(da.p, 0, (long)G), rb = ref(db.p, 0, (long)G), rc = ref(dc.p, 0, (long)G);
+    auto once = [&](int i) {
+        GlweRef src = (i & 1) ? rb : ra, dst = (i & 1) ? ra : rb;
+        if (kind == 0) trace_steps(c, src, dst, rc, 0, n, batch, 1);
+        else ep_chain(c, src, dst, rc, c->d_prep, n, batch, 1);
+    };
+    for (int i = 0; i < 4; i++) once(i);   // warm-up
+    HIPCHK(c, hipEventRecord(c->t0, c->stream));
+    for (int i = 0; i < iters; i++) once(i);
     HIPCHK(c, hipEventRecord(c->t1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->t1));
     HIPCHK(c, hipEventElapsedTime(total_ms, c->t0, c->t1));

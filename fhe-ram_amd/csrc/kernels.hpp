@@ -1040,9 +1040,14 @@ struct KsChainArgs {
     const unsigned* pred = nullptr;  // fallback launch behind k_trace_tail: runs only if *pred == pred_seq (that launch gave up)
     unsigned pred_seq = 0;
     unsigned* host_count = nullptr;  // pinned host word that mirrors the number of fallbacks taken (read by the host without a sync)
-    int yform = 0;                   // 1: the intermediate ciphertexts of the chain are handed over as Y = ceil(A/2) (ks_trace_y); needs n >= 2
 };
-template <int SX, int SK, int SO>
+// YF: the intermediates of the chain are handed over as Y = ceil(A/2) (ks_trace_y).  YF = false is the limb-form chain; it
+// is also what runs as the predicated fallback behind k_trace_tail: that launch normally has nothing to do, but it needs
+// its registers and LDS granted before it can say so, and it must slip in next to the side-stream work that
+// read_prepare_write starts beside the trace chain — with the leaner limb-form kernel (<= 232 VGPRs: two waves leave room
+// on a SIMD) it does; the Y-form kernel, which takes the whole register file, waited for that work to drain (+0.2 ms per
+// read_prepare_write, measured).
+template <int SX, int SK, int SO, bool YF = false>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.pred) {
@@ -1062,14 +1067,11 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) 
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
         __builtin_assume(tid >= 0 && tid < T);
-        if constexpr (SX == 3 && SO == 3) {
-            if (ca.yform) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y)
-                if (i == 0) ks_trace_y<SK, false, true>(ka, lds, true, tid);
-                else if (i + 1 < ca.n) ks_trace_y<SK, true, true>(ka, lds, false, tid);
-                else ks_trace_y<SK, true, false>(ka, lds, false, tid);
-            } else {
-                ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
-            }
+        if constexpr (YF) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y); n >= 2
+            static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
+            if (i == 0) ks_trace_y<SK, false, true>(ka, lds, true, tid);
+            else if (i + 1 < ca.n) ks_trace_y<SK, true, true>(ka, lds, false, tid);
+            else ks_trace_y<SK, true, false>(ka, lds, false, tid);
         } else {
             ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
         }

@@ -159,10 +159,15 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
-    ca.yform = (c->chain_y && n >= 2) ? 1 : 0;
     for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
-    if (c->s_evk == 5) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
-    else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+    const bool yf = c->chain_y && n >= 2;   // intermediates handed over as Y = ceil(A/2) (ks_trace_y)
+    if (c->s_evk == 5) {
+        if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, true>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        else hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+    } else {
+        if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, true>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+    }
 }
 // The latency-bound end of the path (at most 8 ciphertexts, one per XCD): n trace steps as ONE launch with in-kernel
 // hand-offs (k_trace_tail), followed by the fused chain launch that only runs if that one gave up.
@@ -190,7 +195,6 @@ void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int st
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, 0, 0);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
-    ca.yform = (c->chain_y && n >= 2) ? 1 : 0;
     ca.pred = c->d_tail_sync + TAIL_GROUPS * 32; ca.pred_seq = ta.seq; ca.host_count = c->h_tail_fb;
     for (int i = 0; i < n; i++) { ta.key[i] = ca.key[i] = trace_key(c, start + i); ta.ginv[i] = ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
     if (c->s_evk == 5) {

@@ -291,6 +291,11 @@ int fheram_tail_stats(fheram_ctx* ctx, uint64_t* launches, uint64_t* fallbacks);
  * chain, as CoordinatePrepared::product is, coordinate_prepared.rs:147-161), and returns the HIP-event
  * time of the whole chain in ms.  batch = 1 gives the latency of one product, batch >= #CUs the throughput. */
 int fheram_bench_external_product(fheram_ctx* ctx, int batch, int iters, float* total_ms);
+/* The two dependent chains that carry the path's work, on device-resident synthetic operands, `iters` times back to back:
+ * kind 0 = GLWE::trace(0, n) on `batch` ciphertexts (the packer levels in which a row is alone, ram.rs:514, and
+ * write_mid_step's traces, ram.rs:616,621), kind 1 = CoordinatePrepared::product over n digits (coordinate_prepared.rs:147-177).
+ * Returns the HIP-event time of all iterations in ms. */
+int fheram_bench_chain(fheram_ctx* ctx, int kind, int batch, int n, int iters, float* total_ms);
 /* Device properties of the context's GPU (name, CU count) for the bench report. */
 int fheram_device_info(const fheram_ctx* ctx, char* name, size_t name_len, int* compute_units);
 
