@@ -958,17 +958,25 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
     }
     fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before buffer 0 is overwritten
 
+    // the body column, staged for the gathers of add_body — and parked there: its owner takes it back when its turn comes,
+    // so that only ONE column's Y is held in registers during the limb loops (the mask column goes first, from the registers
+    // it already is in)
+    lds_barrier();                     // slower waves may still be inside the wave-local exchanges of the forward transforms
+#pragma unroll
+    for (int k = 0; k < E; k++) bstage[tid + T * k] = y0[k];
+    // published by the barriers of the first inverse transform, which precede every gather
+
     int it = 0;
 #pragma unroll 1
-    for (int co = 0; co < 2; co++) {
+    for (int ci = 0; ci < 2; ci++) {
+        const int co = 1 - ci;
         double cq[E];                  // running quotient of this column's Y: the post-step takes its digits from the least significant one upwards, as the limbs are produced
+        if (co == 1) {
 #pragma unroll
-        for (int k = 0; k < E; k++) cq[k] = (co == 0) ? y0[k] : y1[k];
-        if (co == 0) {                 // the body column, staged for the gathers of add_body
-            lds_barrier();             // slower waves may still be inside the wave-local exchanges of the forward transforms
+            for (int k = 0; k < E; k++) cq[k] = y1[k];
+        } else {
 #pragma unroll
-            for (int k = 0; k < E; k++) bstage[tid + T * k] = y0[k];
-            // published by the barriers of the first inverse transform, which precede every gather
+            for (int k = 0; k < E; k++) cq[k] = bstage[tid + T * k];   // this thread's own slots
         }
         double carry[E], od[E];
 #pragma unroll
@@ -1047,8 +1055,15 @@ struct KsChainArgs {
 // read_prepare_write starts beside the trace chain — with the leaner limb-form kernel (<= 232 VGPRs: two waves leave room
 // on a SIMD) it does; the Y-form kernel, which takes the whole register file, waited for that work to drain (+0.2 ms per
 // read_prepare_write, measured).
+// Register budget: one workgroup per CU, two waves per SIMD.  At 249+ registers the two waves take a SIMD's whole register
+// file, and ANY other wave resident on the CU — the one-wave gate launch that read_prepare_write parks on the side stream is
+// enough — keeps the workgroup off that CU: a 256-workgroup launch on 256 CUs then runs in two rounds (+0.24 ms per
+// read_prepare_write, measured when the Y-form kernel first compiled to 250).  Capped so that a small wave still fits.
+#ifndef FK_CHAIN_VGPRS
+#define FK_CHAIN_VGPRS 120   // the attribute counts in units of two on gfx90a+ (unified VGPR + AGPR file): 120 -> 240 registers: two waves leave 32 registers of a SIMD for a small third one
+#endif
 template <int SX, int SK, int SO, bool YF = false>
-__global__ __launch_bounds__(T, T / 256) void k_keyswitch_chain(KsChainArgs ca) {
+__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.pred) {
         if (__hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
