@@ -29,7 +29,7 @@ import pyoracle as po  # noqa: E402
 from _pkg import load_package  # noqa: E402
 
 
-def run(cycles=1000, sample_every=100, log_max_addr=14, params="source", pool=32, seed=7, progress=None):
+def run(cycles=1000, sample_every=100, log_max_addr=14, params="source", pool=32, seed=7, progress=None, probes=6):
     pkg = load_package()
     crypto = {"k_glwe_pt": 9, "k_evk_trace": 85} if params == "readme" else {}
     max_addr = 1 << log_max_addr
@@ -45,22 +45,38 @@ def run(cycles=1000, sample_every=100, log_max_addr=14, params="source", pool=32
     model = [pkg.expected_plain(int(v), k_pt) for v in data]             # what each byte decrypts to
     idxs = [int(v) for v in rng.integers(0, max_addr, size=pool)]
     addrs = [pkg.Address.encrypt_sk(ram, i, sk, o.source(seed + 100 + 2 * k), o.source(seed + 101 + 2 * k)) for k, i in enumerate(idxs)]
+    # words that are NEVER written: every cycle still rotates their rows forth and back (ram.rs:502-504,644-646) and patches
+    # coefficient 0 of every row (ram.rs:612-630) — their noise is the one that accumulates; a written word is as fresh as
+    # its last write
+    pidx = []
+    while len(pidx) < probes:
+        v = int(rng.integers(0, max_addr))
+        if v not in idxs and v not in pidx:
+            pidx.append(v)
+    paddrs = [pkg.Address.encrypt_sk(ram, i, sk, o.source(seed + 300 + 2 * k), o.source(seed + 301 + 2 * k)) for k, i in enumerate(pidx)]
     vals = rng.integers(0, 256, size=(pool, ws), dtype=np.uint8)
     words = [ram.encrypt_word(sk, vals[k], o.source(seed + 500 + 2 * k), o.source(seed + 501 + 2 * k)) for k in range(pool)]
     bound = -(k_pt + 1.0)
 
+    def read_noise(cycle, addr, idx):
+        ct = ram.read(addr, keys)
+        wants = [model[i + ws * idx] for i in range(ws)]
+        out = []
+        for (value, noise), want in zip(ram.decrypt_coeff(sk, ct, wants), wants):
+            assert value == want, f"cycle {cycle}: address {idx} decrypts to {value}, model says {want}"
+            assert noise < bound, f"cycle {cycle}: noise {noise} >= {bound} (examples/fhe-ram.rs:109-114)"
+            out.append(noise)
+        return out
+
     def sample(cycle, last):
-        worst, per = -1e9, []
+        per = []
         for k in sorted(set([last, (last + 1) % pool, (last + 7) % pool, int(rng.integers(0, pool))])):
-            idx = idxs[k]
-            ct = ram.read(addrs[k], keys)
-            wants = [model[i + ws * idx] for i in range(ws)]
-            for (value, noise), want in zip(ram.decrypt_coeff(sk, ct, wants), wants):
-                assert value == want, f"cycle {cycle}: address {idx} decrypts to {value}, model says {want}"
-                assert noise < bound, f"cycle {cycle}: noise {noise} >= {bound} (examples/fhe-ram.rs:109-114)"
-                per.append(noise)
-                worst = max(worst, noise)
-        return {"cycle": cycle, "max_noise_bits": worst, "mean_noise_bits": float(np.mean(per)), "reads": len(per) // ws}
+            per += read_noise(cycle, addrs[k], idxs[k])
+        unt = []
+        for a, i in zip(paddrs, pidx):
+            unt += read_noise(cycle, a, i)
+        return {"cycle": cycle, "max_noise_bits": max(per + unt), "mean_noise_bits": float(np.mean(per)), "reads": (len(per) + len(unt)) // ws,
+                "never_written_mean_bits": float(np.mean(unt)), "never_written_max_bits": max(unt)}
 
     traj = [sample(0, 0)]
     t0 = time.perf_counter()
@@ -77,15 +93,18 @@ def run(cycles=1000, sample_every=100, log_max_addr=14, params="source", pool=32
             if progress:
                 progress(traj[-1], time.perf_counter() - t0)
     elapsed = time.perf_counter() - t0
-    # noise variance grows linearly with the number of cycles (every cycle adds independent external-product and
-    # key-switch noise to every row): fit 2^(2 noise) = a + b * cycle on the mean noise, extrapolate to the bound
+    # the noise variance of a word that is never written grows linearly with the number of cycles (every cycle adds
+    # independent external-product and key-switch noise to every row): fit 2^(2 noise) = a + b * cycle on its mean noise,
+    # extrapolate to the bound.  (A word that IS written is as noisy as its last write made it: flat.)
     cyc = np.array([t["cycle"] for t in traj], dtype=np.float64)
-    var = np.exp2(2.0 * np.array([t["mean_noise_bits"] for t in traj]))
+    var = np.exp2(2.0 * np.array([t["never_written_mean_bits"] for t in traj]))
     b, a = np.polyfit(cyc, var, 1) if len(traj) > 2 else (0.0, float(var[0]))
-    out = {"what": "read_prepare_write + write cycles on one RAM, random pooled addresses and words; noise of Ram::read results "
-                   "(examples/fhe-ram.rs:230-236 metric), every sample decrypted and checked against a plaintext model",
+    out = {
+           "what": "read_prepare_write + write cycles on one RAM, random pooled addresses and words; noise of Ram::read results "
+                   "(examples/fhe-ram.rs:230-236 metric) at recently written addresses (mean/max_noise_bits) and at addresses that are "
+                   "never written (never_written_*: the noise that accumulates); every sample decrypted and checked against a plaintext model",
            "max_addr": max_addr, "word_size": ws, "params": params, "k_glwe_pt": k_pt, "k_glwe_ct": k_ct, "cycles": cycles,
-           "sample_every": sample_every, "address_pool": pool, "noise_bound_bits": bound,
+           "sample_every": sample_every, "address_pool": pool, "never_written_probes": probes, "noise_bound_bits": bound,
            "worst_noise_bits": max(t["max_noise_bits"] for t in traj), "first": traj[0], "last": traj[-1],
            "seconds": elapsed, "cycles_per_s": cycles / elapsed,
            "fit_variance": {"a": float(a), "b_per_cycle": float(b),
@@ -106,7 +125,8 @@ def main():
     args = ap.parse_args()
 
     def progress(t, el):
-        print(f"cycle {t['cycle']}: max noise {t['max_noise_bits']:.2f} bits, mean {t['mean_noise_bits']:.2f} ({el:.0f} s)", flush=True)
+        print(f"cycle {t['cycle']}: written words {t['mean_noise_bits']:.2f} bits, never written {t['never_written_mean_bits']:.2f} "
+              f"(max {t['never_written_max_bits']:.2f}) ({el:.0f} s)", flush=True)
     out = run(args.cycles, args.sample_every, args.log_max_addr, args.params, progress=progress)
     s = json.dumps(out, indent=1)
     if args.out:

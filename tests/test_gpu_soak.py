@@ -41,4 +41,5 @@ def test_noise_growth_over_consecutive_write_cycles(po, params):
     out = noise_growth_gpu.run(cycles=400, sample_every=50, log_max_addr=14, params=params, pool=16)
     assert out["worst_noise_bits"] < out["noise_bound_bits"]
     assert out["last"]["cycle"] == 400 and len(out["trajectory"]) == 9
+    assert out["last"]["never_written_mean_bits"] > out["first"]["never_written_mean_bits"]      # this is the noise that accumulates
     print({k: out[k] for k in ("worst_noise_bits", "noise_bound_bits", "cycles_per_s", "fit_variance")})
