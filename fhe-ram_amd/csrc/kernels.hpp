@@ -898,7 +898,7 @@ __device__ __forceinline__ double take_digit(double& c) {
     c = q;
     return d;
 }
-template <int SK, bool IN_Y, bool OUT_Y, bool PIPE>
+template <int SK, bool IN_Y, bool OUT_Y>
 __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool load_tw, const int tid) {
     constexpr int SX = 3, SO = 3;
     double* tw = lds;
@@ -965,128 +965,6 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
 #pragma unroll
     for (int k = 0; k < E; k++) bstage[tid + T * k] = y0[k];
     // published by the barriers of the first inverse transform, which precede every gather
-
-    if constexpr (PIPE) {
-        // ---- the 2*SK output limb polynomials as ONE software-pipelined sequence, the two waves of a SIMD out of phase ----
-        // tools/lds_valu_overlap.hip: a CU does overlap LDS exchanges with FP64 butterflies (1.80 us per transform when one
-        // wave of every SIMD computes while the other exchanges, against 2.13-2.43 us when all eight waves alternate in step
-        // — what they do when they run the same code between the same barriers).  The transform of limb q+1 up to its
-        // cross-wave exchange ("start") and the rest of limb q's (its last pass, body add, post-step: "finish") are
-        // independent; between two workgroup barriers every wave does both, but waves 0-3 finish first and then start, while
-        // waves 4-7 (the second wave of each SIMD) start, park the started transform in its wave-local exchange buffer half
-        // way (exchange 1 written, not yet read back), finish limb q, and resume: the LDS phases of one wave of a SIMD fall
-        // into the FP64 phases of the other.  Same operations per limb polynomial, same operands, same order per coefficient.
-        constexpr int NQ = 2 * SK;
-        const bool late = __builtin_amdgcn_readfirstlane((tid >> 8) & 1) != 0;   // waves 4..7: the second wave of every SIMD
-        double cq[E], carry[E], od[E];
-#pragma unroll
-        for (int k = 0; k < E; k++) { cq[k] = y1[k]; carry[k] = 0.0; od[k] = 0.0; }
-        OpRegs g[SX];
-        auto fetch = [&](int q) {
-            const int co = 1 - q / SK, j = SK - 1 - q % SK;
-#pragma unroll
-            for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
-        };
-        double acc[1][E];
-        auto buf_of = [&](int q) { return data + (q & 1) * LDS_DATA; };
-        // start(q), first part: MAC, passes 3 and 2, exchange 2, exchange 1 WRITTEN (wave local)
-        auto start_a = [&](int q) {
-#pragma unroll
-            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
-#pragma unroll
-            for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 1 < NQ) fetch(q + 1);            // the next limb polynomial's operands have a whole interval to arrive
-            double* buf = buf_of(q);
-            TwPass t3, t2;
-            inv_twiddles<3>(t3, tw, tid);
-            inv_pass<3>(acc[0], t3);                  // three MAC terms: no initial reduction (ntt_inv PRE = false)
-            acc[0][0] = reduce(acc[0][0]); acc[0][1] = reduce(acc[0][1]);
-            inv_twiddles<2>(t2, tw, tid);
-            exchange_inv<2, 1>(acc, buf, tid);
-            inv_pass<2>(acc[0], t2);
-            acc[0][0] = reduce(acc[0][0]); acc[0][1] = reduce(acc[0][1]);
-#pragma unroll
-            for (int k = 0; k < E; k++) buf[lay<1>(pat<2>(tid, k))] = acc[0][k];   // exchange 1, write side
-            wave_lds_fence();
-        };
-        // start(q), second part: exchange 1 read back, pass 1, exchange 0 written (its far side is read after the barrier)
-        auto start_b = [&](int q) {
-            double* buf = buf_of(q);
-            TwPass t1;
-            inv_twiddles<1>(t1, tw, tid);
-#pragma unroll
-            for (int k = 0; k < E; k++) acc[0][k] = buf[lay<1>(pat<1>(tid, k))];   // exchange 1, read side
-            inv_pass<1>(acc[0], t1);
-            acc[0][0] = reduce(acc[0][0]); acc[0][1] = reduce(acc[0][1]);
-#pragma unroll
-            for (int k = 0; k < E; k++) buf[lay<0>(pat<1>(tid, k))] = acc[0][k];   // exchange 0, write side (this wave's own region)
-        };
-        // finish(q): far side of exchange 0, pass 0, body add, post-step + normalisation step of limb polynomial q
-        auto finish = [&](int q) {
-            const int co = 1 - q / SK, j = SK - 1 - q % SK;
-            double* buf = buf_of(q);
-            TwPass t0;
-            inv_twiddles<0>(t0, tw, tid);
-#pragma unroll
-            for (int k = 0; k < E; k++) acc[0][k] = buf[lay<0>(pat<0>(tid, k))];   // exchange 0, read side (crosses waves: behind the barrier)
-            inv_pass<0>(acc[0], t0);
-#pragma unroll
-            for (int k = 0; k < E; k++) acc[0][k] = reduce(acc[0][k]);
-            if (co == 0 && j < SX) {   // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
-                int sidx = sidx0;
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    double c = bstage[sidx & (N - 1)];
-                    double d = take_digit(c);
-                    if (j <= 1) d = take_digit(c);
-                    if (j == 0) d = c;
-                    acc[0][k] += (sidx >= N) ? -d : d;
-                    sidx = (sidx + sstep) & (2 * N - 1);
-                }
-            }
-            const double scale = (j == 2) ? 1.0 : ((j == 1) ? TWO_B : TWO_2B);
-#pragma unroll
-            for (int k = 0; k < E; k++) {
-                double v = acc[0][k];
-                if (j < SX) {          // a + phi(KS(a)): limb j of rsh1(a) = digit j of Y
-                    const double xl = (j > 0) ? take_digit(cq[k]) : cq[k];
-                    v += xl;
-                }
-                v += carry[k];
-                const double cy = carry_of(v);
-                carry[k] = cy;
-                if (j < SO) {
-                    const double d = digit_of(v, cy);
-                    if constexpr (OUT_Y) od[k] = __builtin_fma(d, scale, od[k]);
-                    else gstore_i32(op + glwe_off(j, co), (unsigned)(tid + T * k) * 4u, (int)d);
-                }
-            }
-            if (j == 0) {              // the column is complete
-                if constexpr (OUT_Y) {
-                    double* yo = reinterpret_cast<double*>(op) + (long)co * N;
-#pragma unroll
-                    for (int k = 0; k < E; k++) gstore_f64(yo, (unsigned)(tid + T * k) * 8u, __builtin_floor(__builtin_fma(od[k], 0.5, 0.5)));
-                }
-                if (co == 1) {         // on to the body column: its Y comes back from where it was parked
-#pragma unroll
-                    for (int k = 0; k < E; k++) { cq[k] = bstage[tid + T * k]; carry[k] = 0.0; od[k] = 0.0; }
-                }
-            }
-        };
-        fetch(0);
-        // one code site per piece (two for finish): iteration q finishes limb polynomial q and starts q + 1; the first one
-        // only starts, the last one only finishes
-#pragma unroll 1
-        for (int q = -1; q < NQ; q++) {
-            if (q >= 0 && !late) finish(q);
-            if (q + 1 < NQ) start_a(q + 1);
-            if (q >= 0 && late) finish(q);
-            if (q + 1 < NQ) start_b(q + 1);
-            lds_barrier();             // exchange 0 of q + 1 complete; every far-side read of q's is done (its buffer is written again after this barrier only)
-        }
-        return;
-    }
 
     int it = 0;
 #pragma unroll 1
@@ -1171,8 +1049,7 @@ struct KsChainArgs {
     unsigned pred_seq = 0;
     unsigned* host_count = nullptr;  // pinned host word that mirrors the number of fallbacks taken (read by the host without a sync)
 };
-// YF != 0: the intermediates of the chain are handed over as Y = ceil(A/2) (ks_trace_y; 2: with the two waves of a SIMD out
-// of phase).  YF = 0 is the limb-form chain; it
+// YF: the intermediates of the chain are handed over as Y = ceil(A/2) (ks_trace_y).  YF = false is the limb-form chain; it
 // is also what runs as the predicated fallback behind k_trace_tail: that launch normally has nothing to do, but it needs
 // its registers and LDS granted before it can say so, and it must slip in next to the side-stream work that
 // read_prepare_write starts beside the trace chain — with the leaner limb-form kernel (<= 232 VGPRs: two waves leave room
@@ -1185,7 +1062,7 @@ struct KsChainArgs {
 #ifndef FK_CHAIN_VGPRS
 #define FK_CHAIN_VGPRS 120   // the attribute counts in units of two on gfx90a+ (unified VGPR + AGPR file): 120 -> 240 registers: two waves leave 32 registers of a SIMD for a small third one
 #endif
-template <int SX, int SK, int SO, int YF = 0>
+template <int SX, int SK, int SO, bool YF = false>
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.pred) {
@@ -1205,12 +1082,11 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
         __builtin_assume(tid >= 0 && tid < T);
-        if constexpr (YF != 0) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y); n >= 2
+        if constexpr (YF) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y); n >= 2
             static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
-            constexpr bool PIPE = (YF == 2);   // the two waves of a SIMD out of phase (see ks_trace_y)
-            if (i == 0) ks_trace_y<SK, false, true, PIPE>(ka, lds, true, tid);
-            else if (i + 1 < ca.n) ks_trace_y<SK, true, true, PIPE>(ka, lds, false, tid);
-            else ks_trace_y<SK, true, false, PIPE>(ka, lds, false, tid);
+            if (i == 0) ks_trace_y<SK, false, true>(ka, lds, true, tid);
+            else if (i + 1 < ca.n) ks_trace_y<SK, true, true>(ka, lds, false, tid);
+            else ks_trace_y<SK, true, false>(ka, lds, false, tid);
         } else {
             ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
         }

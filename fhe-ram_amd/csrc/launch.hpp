@@ -160,16 +160,13 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
     for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
-    const int yf = n >= 2 ? c->chain_y : 0;   // 1 / 2: intermediates handed over as Y = ceil(A/2) (ks_trace_y; 2: the two waves of a SIMD out of phase)
-    const dim3 grid(gx, gy, 1);
+    const bool yf = c->chain_y && n >= 2;   // intermediates handed over as Y = ceil(A/2) (ks_trace_y)
     if (c->s_evk == 5) {
-        if (yf == 2) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 2>), grid, dim3(T), LDS_BYTES, c->cur, ca);
-        else if (yf == 1) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 1>), grid, dim3(T), LDS_BYTES, c->cur, ca);
-        else hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), grid, dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, true>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        else hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     } else {
-        if (yf == 2) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 2>), grid, dim3(T), LDS_BYTES, c->cur, ca);
-        else if (yf == 1) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 1>), grid, dim3(T), LDS_BYTES, c->cur, ca);
-        else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), grid, dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, true>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }
 }
 // The latency-bound end of the path (at most 8 ciphertexts, one per XCD): n trace steps as ONE launch with in-kernel
