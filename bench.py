@@ -78,7 +78,7 @@ def algorithmic_bytes(max_addr, ws, n_digits, atk_i64=ATK_I64):
     return read, rpw, write
 
 
-PMC_PROFILE = "profiles/r02_pmc_hbm_traffic.json"
+PMC_PROFILE = "profiles/r03_pmc_hbm_traffic.json"
 
 
 def pmc_traffic_per_launch():
@@ -522,7 +522,7 @@ def main():
             avg_ms = kf["ms"] / kf["launches"]
             blocks = kf["blocks"] / kf["launches"]
             bytes_abi = blocks * 2 * GLWE_I64 + atk_i64              # in + out GLWE (int64 limbs) + key once
-            bytes_dev = blocks * 2 * (GLWE_I64 // 2) + atk_i64       # what the device layout must move: int32 limbs, f64 key
+            bytes_dev = blocks * 2 * (GLWE_I64 // 3) + atk_i64       # what the device layout must move per inner step of a chain: Y form (8 B per coefficient and column = 65 536 B per ciphertext) in and out, f64 key
             ach = kf["blocks"] * fp64_per_ks / (kf["ms"] * 1e-3) / 1e12          # T FP64 VALU instructions / s
             chain = classes["keyswitch_chain_launch"]
             # PRIMARY roofline = the roof that binds this kernel: the FP64 vector ALU.  Every FP64 VALU instruction

@@ -66,18 +66,25 @@ out = {"calibration": calib,
 
 def dominant(kern):
     """The dominant kernel shape = one fused trace step over 256 ciphertexts.  It runs inside k_keyswitch_chain (6 or 12 steps
-    per launch at 2^18) or as k_keyswitch<1,3,4,3,2,0>; every step writes exactly blocks * 98 304 B, which gives the steps of a launch."""
-    for pat in ("k_keyswitch_chain<3, 4, 3>", "k_keyswitch<1, 3, 4, 3, 2, 0>"):
-        cand = [(k, e) for k, e in kern.items() if pat in k and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e]
+    per launch at 2^18) or as k_keyswitch<1,3,4,3,2,0>.  Limb-form chain: every step writes blocks * 98 304 B; Y-form chain
+    (round 3: intermediates as one double per coefficient and column): blocks * 65 536 B per inner step, 98 304 B for the last —
+    which gives the steps of a launch from its WRITE_SIZE."""
+    for pat in ("k_keyswitch_chain<3, 4, 3", "k_keyswitch<1, 3, 4, 3, 2, 0>"):
+        cand = [(k, e) for k, e in kern.items() if pat in k and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e
+                and int(k.split("grid_threads=")[1]) >= 65536]
         if cand:
             k, e = max(cand, key=lambda ke: ke[1]["launches"])
             blocks = int(k.split("grid_threads=")[1]) // 512
-            steps = e["write_bytes_per_launch"] / (blocks * 98304.0)
+            yform = ("true" in k.split("grid_threads=")[0]) or ("(bool)1" in k)
+            per_ct = e["write_bytes_per_launch"] / blocks
+            steps = ((per_ct - 98304.0) / 65536.0 + 1.0) if yform else per_ct / 98304.0
+            comp = (2 * 65536 if yform else 2 * 98304)
             return {"kernel": k, "launches": e["launches"], "ciphertexts_per_step": blocks, "steps_per_launch": steps,
+                    "intermediate_form": "Y = ceil(A/2), 8 B per coefficient and column" if yform else "int32 limbs",
                     "read_bytes_per_step": e["read_bytes_per_launch"] / steps, "write_bytes_per_step": e["write_bytes_per_launch"] / steps,
                     "hbm_bytes_per_launch": (e["read_bytes_per_launch"] + e["write_bytes_per_launch"]) / steps,
                     "note": "hbm_bytes_per_launch is per STEP (one trace step over all ciphertexts = what bench.py's roofline calls a launch); "
-                            "compulsory for the int32 device layout: 2 x 98 304 B per ciphertext + the 786 432 B key"}
+                            f"compulsory for the device layout of an inner step: {comp} B per ciphertext + the 786 432 B key"}
     return None
 
 
