@@ -386,6 +386,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tail = ram.tail_stats()       # single-launch trace chains so far (warm-up + timed steps) and how many fell back
+    mid = ram.mid_stats() if hasattr(ram, "mid_stats") else {"launches": 0, "fallbacks": 0}
     # For information only (never `value`): the same K steps enqueued back to back — with a NULL result pointer the ABI's
     # ops return as soon as they are enqueued — and ONE synchronisation at the end, i.e. without the host's round trip
     # between ops that the synchronous calls of the reference interface imply.
@@ -495,7 +496,8 @@ def main():
                                       "gave up (CUs not available side by side) and were redone by the fused launch behind them"),
         "device": ram.device_info(),
     }
-    if tail["fallbacks"] > 0:
+    out["mid_chain"] = dict(mid, note="dependent chains on 9..64 ciphertexts (MAX_ADDR 2^13..2^16) as one launch with in-kernel hand-offs (k_chain_mid)")
+    if tail["fallbacks"] > 0 or mid["fallbacks"] > 0:
         out["trace_tail_degraded"] = True     # silent degradation made visible: some single-launch chains were redone by their fallback
         print(f"bench.py: WARNING: {tail['fallbacks']} of {tail['launches']} single-launch trace chains fell back", file=sys.stderr)
     if boundary is not None:

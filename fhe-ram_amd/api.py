@@ -109,6 +109,7 @@ _SYMBOLS = [
     ("fheram_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("fheram_profile_get", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     ("fheram_tail_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("fheram_mid_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fheram_profile_reset", C.c_int, [C.c_void_p]),
     ("fheram_bench_external_product", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("fheram_bench_chain", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -825,6 +826,12 @@ class Ram:
         """single-launch trace chains since the context was created, and how many of them fell back (fheram_tail_stats)"""
         a, b = C.c_uint64(), C.c_uint64()
         self._chk(library().fheram_tail_stats(self._h, C.byref(a), C.byref(b)))
+        return {"launches": int(a.value), "fallbacks": int(b.value)}
+
+    def mid_stats(self):
+        """single-launch chains on 9..64 ciphertexts since the context was created, and how many fell back (fheram_mid_stats)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(library().fheram_mid_stats(self._h, C.byref(a), C.byref(b)))
         return {"launches": int(a.value), "fallbacks": int(b.value)}
 
     def bench_external_product(self, batch: int, iters: int) -> float:

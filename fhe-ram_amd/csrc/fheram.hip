@@ -116,6 +116,9 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         static std::atomic<int> serial{0};
         c->tail_xoff = ((serial++ + (int)getpid()) & 1) * (TAIL_GROUPS / 2);
         c->tail_test = (tl && tl[0] == '2') ? 1 : ((tl && tl[0] == '3') ? 2 : 0);
+        const char* md = getenv("FHERAM_MID");
+        c->mid = (md && md[0] == '0') ? 0 : 1;
+        c->mid_test = (md && md[0] == '2') ? 1 : 0;
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* cy = getenv("FHERAM_CHAIN_Y");
@@ -142,6 +145,9 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_keyswitch_chain<3, 4, 3, true>));
     LDSATTR((&k_keyswitch_chain<3, 5, 3, true>));
     LDSATTR((&k_trace_tail<3, 4, 3>));
+    LDSATTR((&k_chain_mid<false, 4, 8>)); LDSATTR((&k_chain_mid<false, 4, 4>));
+    LDSATTR((&k_chain_mid<false, 5, 10>)); LDSATTR((&k_chain_mid<false, 5, 5>));
+    LDSATTR((&k_chain_mid<true, 4, 8>)); LDSATTR((&k_chain_mid<true, 4, 4>));
 #define LDSATTR_KS4(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
 #define LDSATTR_KS(M, SX, SK, SO) LDSATTR_KS4(M, SX, SK, SO); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);
@@ -199,6 +205,10 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipEventCreateWithFlags(&c->ev_wdone, hipEventDisableTiming));
     CCHK(hipMalloc(&c->d_tail_sync, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     CCHK(hipMemset(c->d_tail_sync, 0, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
+    for (int i = 0; i < 2; i++) {
+        CCHK(hipMalloc(&c->d_mid_sync[i], (size_t)(MID_GROUPS_MAX + 1) * 32 * sizeof(unsigned)));
+        CCHK(hipMemset(c->d_mid_sync[i], 0, (size_t)(MID_GROUPS_MAX + 1) * 32 * sizeof(unsigned)));
+    }
     CCHK(hipHostMalloc((void**)&c->h_tail_fb, 64, hipHostMallocDefault));
     *c->h_tail_fb = 0;
     CCHK(hipHostMalloc((void**)&c->h_res, (size_t)c->ws * G * sizeof(int64_t), hipHostMallocMapped));
@@ -227,7 +237,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv, c->d_mid_sync[0], c->d_mid_sync[1]};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
     if (c->h_res) hipHostFree(c->h_res);
@@ -664,6 +674,18 @@ int fheram_profile_get(fheram_ctx* c, const char* cls, uint64_t* launches, uint6
     if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
     if (blocks) *blocks = it == c->prof.end() ? 0 : it->second.blocks;
     if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
+    return FHERAM_OK;
+}
+int fheram_mid_stats(fheram_ctx* c, uint64_t* launches, uint64_t* fallbacks) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned fb[2] = {0, 0};
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    for (int i = 0; i < 2; i++)
+        HIPCHK(c, hipMemcpyAsync(&fb[i], c->d_mid_sync[i] + MID_GROUPS_MAX * 32 + 1, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (launches) *launches = c->mid_launches;
+    if (fallbacks) *fallbacks = (uint64_t)fb[0] + fb[1];
     return FHERAM_OK;
 }
 int fheram_tail_stats(fheram_ctx* c, uint64_t* launches, uint64_t* fallbacks) {

@@ -79,9 +79,15 @@ __device__ __forceinline__ long glwe_off(int limb, int col) { return (long)(limb
 #endif
 typedef const __attribute__((address_space(1))) char* gbytes_t;
 typedef __attribute__((address_space(1))) char* gbytes_w_t;
+// a pointer every lane holds the same value of, moved to scalar registers (folds away where the compiler already knows it
+// is uniform; two v_readfirstlane where it does not)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ int gload_i32(const int32_t* base, unsigned byte_off) {
 #if FK_SADDR
-    gbytes_t b = (gbytes_t)reinterpret_cast<const char*>(base);
+    gbytes_t b = (gbytes_t)uniform_u64((unsigned long long)base);
     asm("" : "+s"(b));
     return *(const __attribute__((address_space(1))) int*)(b + byte_off);
 #else
@@ -90,7 +96,7 @@ __device__ __forceinline__ int gload_i32(const int32_t* base, unsigned byte_off)
 }
 __device__ __forceinline__ double gload_f64(const double* base, unsigned byte_off) {
 #if FK_SADDR
-    gbytes_t b = (gbytes_t)reinterpret_cast<const char*>(base);
+    gbytes_t b = (gbytes_t)uniform_u64((unsigned long long)base);
     asm("" : "+s"(b));
     return *(const __attribute__((address_space(1))) double*)(b + byte_off);
 #else
@@ -99,7 +105,7 @@ __device__ __forceinline__ double gload_f64(const double* base, unsigned byte_of
 }
 __device__ __forceinline__ void gstore_f64(double* base, unsigned byte_off, double v) {
 #if FK_SADDR
-    gbytes_w_t b = (gbytes_w_t)reinterpret_cast<char*>(base);
+    gbytes_w_t b = (gbytes_w_t)uniform_u64((unsigned long long)base);
     asm("" : "+s"(b));
     *(__attribute__((address_space(1))) double*)(b + byte_off) = v;
 #else
@@ -108,7 +114,7 @@ __device__ __forceinline__ void gstore_f64(double* base, unsigned byte_off, doub
 }
 __device__ __forceinline__ void gstore_i32(int32_t* base, unsigned byte_off, int v) {
 #if FK_SADDR
-    gbytes_w_t b = (gbytes_w_t)reinterpret_cast<char*>(base);
+    gbytes_w_t b = (gbytes_w_t)uniform_u64((unsigned long long)base);
     asm("" : "+s"(b));
     *(__attribute__((address_space(1))) int*)(b + byte_off) = v;
 #else
@@ -180,7 +186,7 @@ __device__ __forceinline__ void load_ops(OpRegs& o, const double* __restrict__ g
     asm("" : "+v"(off));   // opaque per call: the zero extension of the offset must stay next to the loads (not hoisted out of the limb loop) for the scalar-base form to be selected
 #pragma unroll
     for (int kk = 0; kk < E / 2; kk++) {
-        gbytes base = (gbytes)reinterpret_cast<const char*>(g) + (size_t)kk * T * 16;
+        gbytes base = (gbytes)uniform_u64((unsigned long long)g + (unsigned long long)kk * T * 16);
         asm("" : "+s"(base));
         const d2v w = *(gwords)(base + off);
         o.v[kk].x = w.x;
@@ -411,10 +417,16 @@ struct EpChainArgs {
     const double* ggsw[CHAIN_MAX];   // prepared digits
     const double* tw;
     int n;
+    const unsigned* pred = nullptr;  // fallback launch behind k_chain_mid: runs only if *pred == pred_seq (that launch gave up)
+    unsigned pred_seq = 0;
 };
 template <int SA, int SG>
 __global__ __launch_bounds__(T, T / 256) void k_ext_product_chain(EpChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (ca.pred) {
+        if (__hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(const_cast<unsigned*>(ca.pred) + 1, 1u);   // fallbacks taken
+    }
     GlweRef in = ca.src;
 #pragma unroll 1
     for (int i = 0; i < ca.n; i++) {
@@ -1648,6 +1660,248 @@ __global__ __launch_bounds__(256) void k_sub_add_norm(GlweRef a, GlweRef b, Glwe
         for (int j = 0; j < S; j++) op[glwe_off(j, col) + i] = (int)out_l[j];
     }
 }
+// ---------------------------------------------------------------------------------------
+// k_chain_mid (round 3): a dependent chain of n steps on 9..64 ciphertexts — too many for k_trace_tail's one group per XCD,
+// too few to fill the chip with one workgroup per ciphertext (the source default 2^14 has 16 ciphertexts per round, 2^16 has
+// 64: ten / eight alone packer levels and the four products of coordinate 0, each a pair of launches per step before) — as
+// ONE launch with in-kernel hand-offs, by the mechanism of k_trace_tail: the MEMBERS workgroups of a ciphertext sit on one XCD
+// (block b runs on XCD b % 8; checked, not assumed), meet at a counter in that XCD's L2 and read each other's data past
+// their L1; every wait is bounded, a group that cannot meet raises the abort word and the fused chain launch enqueued behind
+// (predicated on it) redoes the chain from the untouched source.
+//   member m of a ciphertext produces LPM = 2*SK / MEMBERS of the 2*SK un-normalised output limb polynomials (all forward
+//     transforms of the input + MAC + one inverse transform per polynomial), stores them as doubles;       hand-off A
+//   normalisation phase: one thread per (column, coefficient), MEMBERS * T threads per ciphertext;          hand-off B
+// Intermediate ciphertexts travel in the one-double form of ks_trace_y: TRACE: Y = ceil(A/2) (the consumer wants rsh1 of the
+// previous output: its digits ARE the digits of Y); EP: A itself (the consumer wants the digits of the previous output).
+// Same sums, same carry chain per coefficient as the fused kernels: bit-identical results.
+//   grid: 256 blocks; XCD x = b % 8, i = b / 8; slot = i / MEMBERS, member = i % MEMBERS; ciphertext = slot * 8 + x
+// ---------------------------------------------------------------------------------------
+constexpr int MID_GROUPS_MAX = 64;
+struct MidArgs {
+    GlweRef src, buf[2];             // step i writes buf[i & 1] (buf[0] must not be the source; the source is never written)
+    const double* opnd[CHAIN_MAX];   // TRACE: prepared trace key of step i;  EP: prepared GGSW digit i
+    int ginv[CHAIN_MAX];             // TRACE: g_i^-1 mod 2N
+    const double* tw;
+    double* big;                     // [ciphertext] x BIG_STRIDE doubles: the un-normalised limb polynomials [col][limb][N]
+    unsigned* sync;                  // [MID_GROUPS_MAX][32] words (arrivals, leavers, XCC mask) + [abort generation, fallbacks taken]
+    unsigned seq;                    // generation of this launch (never 0)
+    int n, n_ct, gx;                 // steps, ciphertexts, ciphertexts per row of the (x, y) grid the GlweRefs are indexed by
+    int rot_mul, rot_base;           // TRACE: the first step reads its input rotated by X^-(rot_base + x * rot_mul)  (write path)
+    int give_up_at;                  // test hook: member 1 of ciphertext 0 gives up at this step (-1: never)
+};
+template <bool EP, int SK, int MEMBERS>
+__global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int SX = 3, SO = 3, NP = 2 * SK;
+    static_assert(NP % MEMBERS == 0 && MEMBERS <= 32, "members per ciphertext");
+    constexpr int LPM = NP / MEMBERS;          // output limb polynomials per member
+    constexpr int GPX = 32 / MEMBERS;          // ciphertexts per XCD
+    const int xcd = (int)blockIdx.x % 8, bi = (int)blockIdx.x / 8;
+    const int slot = bi / MEMBERS, m = bi % MEMBERS;
+    const int ctg = slot * 8 + xcd;            // ciphertext (group) of this workgroup
+    if (slot >= GPX || ctg >= ma.n_ct) return;
+    const int tid = threadIdx.x;
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    double* stage0 = data;                     // exchange buffer 0, before the transforms: the mask column (TRACE) in the one-double form
+    double* stage1 = data + 2 * LDS_DATA;      // third buffer, after the forward transforms: the body column (TRACE, members that add it)
+    int* flag = reinterpret_cast<int*>(lds + LDS_TW + BMAX * LDS_DATA - 2);   // the padding at the very end of the LDS allocation
+    unsigned* ctr = ma.sync + ctg * 32;
+    unsigned* abortp = ma.sync + MID_GROUPS_MAX * 32;
+    const long cty = (long)(ctg / ma.gx), ctx_ = (long)(ctg % ma.gx);
+    double* bigg = ma.big + (long)ctg * BIG_STRIDE;
+    if (tid == 0) {
+        __hip_atomic_fetch_or(ctr + 2, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // performed before this workgroup's first arrival is counted
+    }
+    load_twiddles(tw, ma.tw, tid);
+    bool needs_body = false;                   // TRACE: does this member produce a polynomial of column 0 with limb index < SX?
+    if constexpr (!EP) {
+#pragma unroll
+        for (int l = 0; l < LPM; l++) { const int pi = m * LPM + l; if (pi / SK == 0 && (SK - 1 - pi % SK) < SX) needs_body = true; }
+    }
+    unsigned epoch = 0;
+#pragma unroll 1
+    for (int s = 0; s < ma.n; s++) {
+        const GlweRef rin = (s == 0) ? ma.src : ma.buf[(s - 1) & 1];
+        const GlweRef rout = ma.buf[s & 1];
+        const int32_t* ap = rin.p + cty * rin.sy + ctx_ * rin.sx;
+        int32_t* op = rout.p + cty * rout.sy + ctx_ * rout.sx;
+        const double* yin = reinterpret_cast<const double*>(ap);     // inner steps: [col][N] doubles in the ciphertext's slot
+        double* yout = reinterpret_cast<double*>(op);
+        const bool first = (s == 0), last = (s + 1 == ma.n);
+        const int ginv = EP ? 1 : ma.ginv[s];
+        const int rho = -(ma.rot_base + (int)ctx_ * ma.rot_mul);     // first TRACE step only
+        const int sidx0 = (tid * ginv) & (2 * N - 1), sstep = (T * ginv) & (2 * N - 1);
+        // the one-double form of column `col` at natural coefficient i: A (EP) or Y = ceil(A/2) (TRACE)
+        auto one_double = [&](int col, int i) -> double {
+            if (!first) return ld_l2(yin + (long)col * N + i);       // written by the other members of the group: past the L1
+            int src = i; bool neg = false;
+            if constexpr (!EP) rot_src(i, rho, src, neg);
+            double a = __builtin_fma(__builtin_fma((double)ap[glwe_off(0, col) + src], TWO_B, (double)ap[glwe_off(1, col) + src]), TWO_B,
+                                     (double)ap[glwe_off(2, col) + src]);
+            if constexpr (EP) return a;
+            a = neg ? -a : a;
+            return __builtin_floor(__builtin_fma(a, 0.5, 0.5));
+        };
+        // the operands of the member's first polynomial are requested before anything else: they arrive during phase 1
+        OpRegs g[SX];
+        auto fetch = [&](int l, int cin) {
+            const int pi = m * LPM + l, co = pi / SK, j = SK - 1 - pi % SK;
+#pragma unroll
+            for (int r = 0; r < SX; r++)
+                load_ops(g[r], ma.opnd[s] + (long)(((EP ? (2 * r + cin) : r) * SK + j) * 2 + co) * N, tid);
+        };
+        // (requested after phase 1: held across the batched forward transforms the 48 operand registers spill)
+        // ---- phase 1: inputs; their digits (TRACE: seen through phi_g); forward transforms
+        double xh[EP ? 2 * SX : SX][E];
+        double vb[E];                          // TRACE: the body column at this thread's natural coefficients (members that add it)
+        if constexpr (EP) {
+            // one column at a time: the second column's digits are loaded after the first one's transforms
+#pragma unroll
+            for (int col = 0; col < 2; col++) {
+                if (first) {                   // the limbs as they are stored (they need not be normalised: a rotation's negation leaves +2^16)
+#pragma unroll
+                    for (int k = 0; k < E; k++)
+#pragma unroll
+                        for (int q = 0; q < SX; q++) xh[col * SX + q][k] = (double)ap[glwe_off(q, col) + tid + T * k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < E; k++) {
+                        double c = one_double(col, tid + T * k);
+                        xh[col * SX + 2][k] = take_digit(c); xh[col * SX + 1][k] = take_digit(c); xh[col * SX][k] = c;
+                    }
+                }
+                fwd_all<SX>(*reinterpret_cast<double(*)[SX][E]>(&xh[col * SX]), tw, data, tid);
+            }
+            fetch(0, 0);
+        } else {
+            lds_barrier();                     // the previous step's last inverse transform may still be read across waves in buffer 0
+#pragma unroll
+            for (int k = 0; k < E; k++) stage0[tid + T * k] = one_double(1, tid + T * k);
+            if (needs_body) {
+#pragma unroll
+                for (int k = 0; k < E; k++) vb[k] = one_double(0, tid + T * k);
+            }
+            __syncthreads();
+            int sidx = sidx0;
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const bool ng = sidx >= N;
+                double c = stage0[sidx & (N - 1)];
+                const double d2 = take_digit(c), d1 = take_digit(c);
+                xh[2][k] = ng ? -d2 : d2; xh[1][k] = ng ? -d1 : d1; xh[0][k] = ng ? -c : c;
+                sidx = (sidx + sstep) & (2 * N - 1);
+            }
+            fwd_all<SX>(*reinterpret_cast<double(*)[SX][E]>(&xh[0]), tw, data, tid);   // starts with a barrier: every gather is done
+            fetch(0, 0);
+            if (needs_body) {                  // the body column, staged for the gathers below (the forward transforms used all three buffers)
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < E; k++) stage1[tid + T * k] = vb[k];
+                // published by the barrier at the start of the first inverse transform
+            }
+        }
+        // ---- phase 2: this member's output limb polynomials, un-normalised
+#pragma unroll 1
+        for (int l = 0; l < LPM; l++) {
+            const int pi = m * LPM + l, co = pi / SK, j = SK - 1 - pi % SK;
+            double acc[1][E];
+#pragma unroll
+            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+            if constexpr (EP) {
+#pragma unroll
+                for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(l, 1);                                         // column_in 1 (one exposed round trip per polynomial)
+#pragma unroll
+                for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[SX + r], g[r]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (l + 1 < LPM) fetch(l + 1, 0);                    // the next polynomial's operands arrive during the inverse transform
+                ntt_inv<1, true, true>(acc, tw, data, tid);          // six MAC terms: with the initial reduction
+            } else {
+#pragma unroll
+                for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (l + 1 < LPM) fetch(l + 1, 0);
+                ntt_inv<1, true, false>(acc, tw, data, tid);         // three MAC terms: none
+                if (co == 0 && j < SX) {       // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
+                    int sidx = sidx0;
+#pragma unroll
+                    for (int k = 0; k < E; k++) {
+                        double c = stage1[sidx & (N - 1)];
+                        double d = take_digit(c);
+                        if (j <= 1) d = take_digit(c);
+                        if (j == 0) d = c;
+                        acc[0][k] += (sidx >= N) ? -d : d;
+                        sidx = (sidx + sstep) & (2 * N - 1);
+                    }
+                }
+            }
+            double* bgp = bigg + (long)(co * SK + j) * N;
+#pragma unroll
+            for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
+        }
+        if (ma.give_up_at == s && ctg == 0 && m == 1 % MEMBERS) {
+            if (tid == 0) __hip_atomic_store(abortp, ma.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (!tail_barrier(ctr, abortp, ma.seq, (++epoch) * MEMBERS, flag, s == 0, tid)) break;
+        // ---- normalisation phase: one thread per (column, coefficient): same arithmetic as the emit step of the fused kernels
+#pragma unroll 1
+        for (int item = m * T + tid; item < 2 * N; item += MEMBERS * T) {
+            const int nco = item / N, i = item % N;
+            const double* bgp = bigg + (long)nco * SK * N + i;
+            double cq = 0.0;                   // TRACE: the running quotient of Y at this coefficient (post-step operand)
+            if constexpr (!EP) {
+                if (!first) cq = ld_l2(yin + (long)nco * N + i);
+                else {
+                    int src; bool neg;
+                    rot_src(i, rho, src, neg);
+                    double a = __builtin_fma(__builtin_fma((double)ap[glwe_off(0, nco) + src], TWO_B, (double)ap[glwe_off(1, nco) + src]), TWO_B,
+                                             (double)ap[glwe_off(2, nco) + src]);
+                    a = neg ? -a : a;
+                    cq = __builtin_floor(__builtin_fma(a, 0.5, 0.5));
+                }
+            }
+            double carry = 0.0, ad = 0.0;
+            int dig[SO];
+#pragma unroll
+            for (int q = SK - 1; q >= 0; q--) {
+                double v = ld_l2(bgp + (long)q * N);
+                if constexpr (!EP) {
+                    if (q < SX) v += (q > 0) ? take_digit(cq) : cq;
+                }
+                v += carry;
+                const double cy = carry_of(v);
+                carry = cy;
+                if (q < SO) {
+                    const double d = digit_of(v, cy);
+                    dig[q < SO ? q : 0] = (int)d;
+                    ad = __builtin_fma(d, (q == 2) ? 1.0 : ((q == 1) ? TWO_B : TWO_2B), ad);
+                }
+            }
+            if (last) {
+#pragma unroll
+                for (int q = 0; q < SO; q++) op[glwe_off(q, nco) + i] = dig[q];
+            } else {
+                yout[(long)nco * N + i] = EP ? ad : __builtin_floor(__builtin_fma(ad, 0.5, 0.5));
+            }
+        }
+        if (!last && !tail_barrier(ctr, abortp, ma.seq, (++epoch) * MEMBERS, flag, false, tid)) break;
+    }
+    // the last workgroup of the group to leave rewinds the group's words for the next launch (as k_trace_tail)
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(MEMBERS - 1)) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // int32 device limbs -> int64 host layout, written straight into pinned host memory (the result of a read)
 __global__ __launch_bounds__(256) void k_export_i64(const int32_t* __restrict__ src, long long* __restrict__ dst, int n4) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -285,6 +285,9 @@ int fheram_profile_reset(fheram_ctx* ctx);
  * launch enqueued behind it redoes the chain, with the same result.  launches = such launches since the context was
  * created, fallbacks = how many of them gave up.  Waits for the context's stream. */
 int fheram_tail_stats(fheram_ctx* ctx, uint64_t* launches, uint64_t* fallbacks);
+/* The same for the dependent chains on 9..64 ciphertexts (the alone packer levels, CoordinatePrepared::product and
+ * write_mid_step's traces at MAX_ADDR = 2^13 .. 2^16), which run as one launch with in-kernel hand-offs too (k_chain_mid). */
+int fheram_mid_stats(fheram_ctx* ctx, uint64_t* launches, uint64_t* fallbacks);
 /* BASELINE.json configs[1]: one GLWE x GGSW external product at N = 4096 on device-resident synthetic
  * operands (normalised limbs; the work is data independent).  Runs `iters` launches of `batch` products
  * back to back on the context's stream, each launch consuming the previous one's output (a dependent

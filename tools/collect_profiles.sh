@@ -30,8 +30,8 @@ python bench.py --log-max-addr 21 --steps 5 --no-cpu-baseline > $O/bench_2_21.js
 python bench.py --workload ep > $O/bench_ep.json 2> $O/bench_ep.err
 python bench.py --params readme > $O/bench_readme.json 2> $O/bench_readme.err
 python tools/chain_bench.py 256 600 > $O/chain_bench.txt 2>&1
-( echo "# python bench.py --log-max-addr K --steps 20 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary   (one MI355X, WORDSIZE 4)"; echo "log2(MAX_ADDR)  read_ms  rpw_ms  write_ms  ms_per_step  RAM ops/s  single-launch trace chains / fallbacks";
-  for K in 12 14 16 18 20 21 22 24; do ST=20; [ $K -ge 22 ] && ST=4; python bench.py --log-max-addr $K --steps $ST --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%6d %10.3f %9.3f %9.3f %10.3f %10.1f   %d/%d' % ($K, d['read_ms'], d['read_prepare_write_ms'], d['write_ms'], d['ms_per_step'], d['value'], d['trace_tail']['launches'], d['trace_tail']['fallbacks']))"; done ) > $O/size_sweep.txt
+( echo "# python bench.py --log-max-addr K --steps 20 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary   (one MI355X, WORDSIZE 4)"; echo "log2(MAX_ADDR)  read_ms  rpw_ms  write_ms  ms_per_step  RAM ops/s  single-launch trace chains / fallbacks   mid-batch chains / fallbacks";
+  for K in 12 14 16 18 20 21 22 24; do ST=20; [ $K -ge 22 ] && ST=4; python bench.py --log-max-addr $K --steps $ST --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%6d %10.3f %9.3f %9.3f %10.3f %10.1f   %d/%d   %d/%d' % ($K, d['read_ms'], d['read_prepare_write_ms'], d['write_ms'], d['ms_per_step'], d['value'], d['trace_tail']['launches'], d['trace_tail']['fallbacks'], d['mid_chain']['launches'], d['mid_chain']['fallbacks']))"; done ) > $O/size_sweep.txt
 ./tools/ntt_bench > $O/ntt_bench.txt 2>&1
 ./tools/xcd_handoff > $O/xcd_handoff.txt 2>&1
 ./tools/xcd_barrier > $O/xcd_barrier.txt 2>&1
