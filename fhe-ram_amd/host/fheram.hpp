@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace fheram {
@@ -35,6 +36,13 @@ struct Parameters {
         p.max_addr = max_addr;
         p.n_decomp = (uint32_t)decomp_n.size();
         for (size_t i = 0; i < decomp_n.size() && i < 16; i++) p.decomp_n[i] = decomp_n[i];
+    }
+    // the block README.md:36's timings were taken with (README.md:20-33): K_GLWE_PT 9, 5-limb trace keys, MAX_ADDR 2^18
+    static Parameters readme() {
+        Parameters q(4, {4, 4, 4, 4}, (size_t)1 << 18);
+        q.p.k_glwe_pt = 9;
+        q.p.k_evk_trace = 5 * q.p.base2k;
+        return q;
     }
     size_t max_addr() const { return p.max_addr; }            // parameters.rs:237
     size_t word_size() const { return p.word_size; }          // parameters.rs:261
@@ -130,6 +138,13 @@ public:
         chk(fheram_write(ctx_, flat.data(), (int)w.size(), dev(address)));
     }
     bool state() const { return fheram_ram_state(ctx_) != 0; }                    // SubRam::state, ram.rs:302
+    // The result of the last read / read_prepare_write where the device left it: [word_size][GLWE] int64 in the context's
+    // pinned host buffer (no copy on the host); valid until the next operation on this Ram.
+    const int64_t* result_view() {
+        const int64_t* v = nullptr;
+        chk(fheram_result_map(ctx_, &v));
+        return v;
+    }
 
     // ---- setup side on the device (include/fheram.h, "Setup side on the device") -------------------
     // GLWESecret + GLWESecretPrepared, examples/fhe-ram.rs:49-59
@@ -233,6 +248,74 @@ private:
         chk(fheram_address_create(ctx_, ptr.data(), (int)ptr.size(), &a.h_));     // layout check of ram.rs:404
         a.owner_ = this;
         return a.h_;
+    }
+    std::vector<Glwe> split(const std::vector<int64_t>& flat) const {
+        std::vector<Glwe> out;
+        const size_t g = glwe_len();
+        for (size_t i = 0; i < params.word_size(); i++) out.emplace_back(flat.begin() + i * g, flat.begin() + (i + 1) * g);
+        return out;
+    }
+};
+
+// Ram (ram.rs:25-29) over several GPUs of one node behind ONE handle: the native row-sharded path (fheram_group_*) for a
+// single-process host.  Same three calls, one per op; `devices` a power of two of HIP device indices.
+class GroupRam {
+public:
+    Parameters params;
+    GroupRam(const Parameters& prm, const std::vector<int>& devices) : params(prm) {
+        int rc = fheram_group_create(&params.p, devices.data(), (int)devices.size(), &grp_);
+        if (rc != FHERAM_OK) throw Error(rc, fheram_group_last_error(nullptr));
+    }
+    GroupRam(const GroupRam&) = delete;
+    ~GroupRam() {
+        for (auto& kv : addr_) fheram_group_address_destroy(kv.second);
+        if (grp_) fheram_group_destroy(grp_);
+    }
+    int size() const { return fheram_group_size(grp_); }
+    size_t glwe_len() const { return fheram_glwe_len(fheram_group_ctx(grp_, 0)); }
+    // the whole RAM [word_size][rows][GLWE] (Ram::encrypt_sk output, ram.rs:129-167); scattered by shard
+    void load_encrypted(const std::vector<int64_t>& rows) { chk(fheram_group_ram_upload(grp_, rows.data())); }
+    std::vector<Glwe> read(Address& address, const EvaluationKeysPrepared& keys) {                   // ram.rs:172-191
+        use(keys);
+        std::vector<int64_t> out(params.word_size() * glwe_len());
+        chk(fheram_group_read(grp_, dev(address), out.data()));
+        return split(out);
+    }
+    std::vector<Glwe> read_prepare_write(Address& address, const EvaluationKeysPrepared& keys) {     // ram.rs:196-222
+        use(keys);
+        std::vector<int64_t> out(params.word_size() * glwe_len());
+        chk(fheram_group_read_prepare_write(grp_, dev(address), out.data()));
+        return split(out);
+    }
+    void write(const std::vector<Glwe>& w, Address& address, const EvaluationKeysPrepared& keys) {   // ram.rs:226-294
+        use(keys);
+        std::vector<int64_t> flat;
+        for (auto& g : w) flat.insert(flat.end(), g.begin(), g.end());
+        chk(fheram_group_write(grp_, flat.data(), (int)w.size(), dev(address)));
+    }
+    bool state() const { return fheram_group_ram_state(grp_) != 0; }
+
+private:
+    fheram_group* grp_ = nullptr;
+    const EvaluationKeysPrepared* keys_ = nullptr;
+    std::vector<std::pair<const Address*, fheram_group_addr*>> addr_;   // replicated device copies, by host address object
+    void chk(int rc) { if (rc != FHERAM_OK) throw Error(rc, fheram_group_last_error(grp_)); }
+    void use(const EvaluationKeysPrepared& k) {
+        if (keys_ == &k) return;
+        std::vector<const int64_t*> ptr;
+        for (auto& a : k.atk_glwe) ptr.push_back(a.data());
+        chk(fheram_group_keys_load(grp_, k.gal_els.data(), (int)k.gal_els.size(), ptr.data(), k.atk_ggsw_inv.data(), k.atk_ggsw_inv_p,
+                                   k.tsk_ggsw_inv.data()));
+        keys_ = &k;
+    }
+    fheram_group_addr* dev(const Address& a) {
+        for (auto& kv : addr_) if (kv.first == &a) return kv.second;
+        std::vector<const int64_t*> ptr;
+        for (auto& d : a.digits) ptr.push_back(d.data());
+        fheram_group_addr* h = nullptr;
+        chk(fheram_group_address_create(grp_, ptr.data(), (int)ptr.size(), &h));
+        addr_.emplace_back(&a, h);
+        return h;
     }
     std::vector<Glwe> split(const std::vector<int64_t>& flat) const {
         std::vector<Glwe> out;

@@ -12,6 +12,8 @@ struct ZeroSource : fheram::Source {
 int main() {
     fheram::Parameters p;
     if (p.max_addr() != (1u << 14) || p.word_size() != 4 || p.basek() != 17) return 2;   // parameters.rs:11-21
+    fheram::Parameters rd = fheram::Parameters::readme();                                    // README.md:20-33
+    if (rd.max_addr() != (1u << 18) || rd.k_glwe_pt() != 9 || rd.p.k_evk_trace != 5 * 17) return 2;
     try {
         fheram::Ram ram = fheram::Ram::new_from_ram_params(4, {3, 3, 3, 3}, 1 << 12);
         fheram::EvaluationKeysPrepared keys;
@@ -36,6 +38,14 @@ int main() {
             if (((got - want) & ((1 << 17) - 1)) != 0) { std::printf("word %zu: got %lld want %lld\n", i, (long long)got, (long long)want); return 5; }
         }
         std::printf("device-side setup + read + decrypt: ok\n");
+        {   // the result in place (pinned host buffer the device wrote): the same limbs as the copy returned by read
+            std::vector<fheram::Glwe> r = ram.read(addr, keys);
+            const int64_t* v = ram.result_view();
+            for (size_t i = 0; i < r.size(); i++)
+                for (size_t k = 0; k < r[i].size(); k++)
+                    if (v[i * r[i].size() + k] != r[i][k]) { std::printf("result_view differs\n"); return 7; }
+            std::printf("result in place == result copied: ok\n");
+        }
         // Address::set_from_fheuint (conversion.rs:68-82): the same word through an address derived from an encrypted integer
         fheram::Ram::FheUintPrepared fu(ram, idx, dsk, xa, xe, 12);
         fheram::Address derived;
@@ -44,6 +54,12 @@ int main() {
         for (size_t i = 0; i < 4; i++)
             if (((pt2[i * 3 * p.n()] - pt[i * 3 * p.n()]) & ((1 << 17) - 1)) != 0) { std::printf("derived address: word %zu differs\n", i); return 6; }
         std::printf("address derived from an encrypted integer reads the same word: ok\n");
+        // one handle over "two GPUs" (the same device twice: rehearsal): a group must refuse an operation before its keys
+        // and RAM are loaded exactly as the single context does
+        fheram::GroupRam grp(fheram::Parameters(4, {3, 3, 3, 3}, 1 << 12), {0, 0});
+        if (grp.size() != 2) return 8;
+        try { fheram::Address a2; grp.read(a2, fheram::EvaluationKeysPrepared()); return 9; }
+        catch (const fheram::Error& e) { std::printf("group refused as the reference would: %s\n", e.what()); }
     } catch (const fheram::Error& e) {
         if (e.code != FHERAM_ERR_DEVICE) return 4;
         std::printf("no GPU: %s\n", e.what());
