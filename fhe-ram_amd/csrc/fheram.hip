@@ -145,9 +145,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_keyswitch_chain<3, 4, 3, true>));
     LDSATTR((&k_keyswitch_chain<3, 5, 3, true>));
     LDSATTR((&k_trace_tail<3, 4, 3>));
-    LDSATTR((&k_chain_mid<false, 4, 8>)); LDSATTR((&k_chain_mid<false, 4, 4>));
-    LDSATTR((&k_chain_mid<false, 5, 10>)); LDSATTR((&k_chain_mid<false, 5, 5>));
-    LDSATTR((&k_chain_mid<true, 4, 8>)); LDSATTR((&k_chain_mid<true, 4, 4>));
+    LDSATTR((&k_chain_mid<false, 4>)); LDSATTR((&k_chain_mid<false, 5>)); LDSATTR((&k_chain_mid<true, 4>));
 #define LDSATTR_KS4(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
 #define LDSATTR_KS(M, SX, SK, SO) LDSATTR_KS4(M, SX, SK, SO); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);
@@ -208,6 +206,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     for (int i = 0; i < 2; i++) {
         CCHK(hipMalloc(&c->d_mid_sync[i], (size_t)(MID_GROUPS_MAX + 1) * 32 * sizeof(unsigned)));
         CCHK(hipMemset(c->d_mid_sync[i], 0, (size_t)(MID_GROUPS_MAX + 1) * 32 * sizeof(unsigned)));
+        CCHK(hipMalloc(&c->d_mid_y[i], (size_t)2 * MID_GROUPS_MAX * 2 * N * sizeof(double)));
     }
     CCHK(hipHostMalloc((void**)&c->h_tail_fb, 64, hipHostMallocDefault));
     *c->h_tail_fb = 0;
@@ -237,7 +236,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv, c->d_mid_sync[0], c->d_mid_sync[1]};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv, c->d_mid_sync[0], c->d_mid_sync[1], c->d_mid_y[0], c->d_mid_y[1]};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
     if (c->h_res) hipHostFree(c->h_res);

@@ -412,20 +412,21 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
 // the steps need no device-wide synchronisation — what a sequence of launches pays per step (kernel drain and
 // ramp, kernel arguments, the twiddle table, a cold first load: 5-6 us of 55) is paid once.
 constexpr int CHAIN_MAX = 12;
+constexpr int MID_GROUPS_MAX = 16;   // ciphertexts of a k_chain_mid launch (two per XCD)
 struct EpChainArgs {
     GlweRef src, buf[2];             // step i writes buf[i & 1] (buf[0] must not be src)
     const double* ggsw[CHAIN_MAX];   // prepared digits
     const double* tw;
     int n;
-    const unsigned* pred = nullptr;  // fallback launch behind k_chain_mid: runs only if *pred == pred_seq (that launch gave up)
-    unsigned pred_seq = 0;
+    unsigned* done = nullptr;        // fallback launch behind k_chain_mid: a ciphertext is redone unless done[ct * 32 + 3] == done_seq
+    unsigned done_seq = 0;
 };
 template <int SA, int SG>
 __global__ __launch_bounds__(T, T / 256) void k_ext_product_chain(EpChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (ca.pred) {
-        if (__hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(const_cast<unsigned*>(ca.pred) + 1, 1u);   // fallbacks taken
+    if (ca.done) {
+        if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
+        if (threadIdx.x == 0) atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u);   // ciphertexts redone (fheram_mid_stats)
     }
     GlweRef in = ca.src;
 #pragma unroll 1
@@ -1060,6 +1061,8 @@ struct KsChainArgs {
     const unsigned* pred = nullptr;  // fallback launch behind k_trace_tail: runs only if *pred == pred_seq (that launch gave up)
     unsigned pred_seq = 0;
     unsigned* host_count = nullptr;  // pinned host word that mirrors the number of fallbacks taken (read by the host without a sync)
+    unsigned* done = nullptr;        // fallback launch behind k_chain_mid: a ciphertext is redone unless done[ct * 32 + 3] == done_seq
+    unsigned done_seq = 0;
 };
 // YF: the intermediates of the chain are handed over as Y = ceil(A/2) (ks_trace_y).  YF = false is the limb-form chain; it
 // is also what runs as the predicated fallback behind k_trace_tail: that launch normally has nothing to do, but it needs
@@ -1083,6 +1086,10 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
             const unsigned taken = atomicAdd(const_cast<unsigned*>(ca.pred) + 1, 1u) + 1u;   // fallbacks taken (fheram_tail_stats)
             if (ca.host_count) __hip_atomic_store(ca.host_count, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+    if (ca.done) {
+        if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
+        if (threadIdx.x == 0) atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u);   // ciphertexts redone (fheram_mid_stats)
     }
     KsArgs ka = ca.base;
 #pragma unroll 1
@@ -1661,77 +1668,109 @@ __global__ __launch_bounds__(256) void k_sub_add_norm(GlweRef a, GlweRef b, Glwe
     }
 }
 // ---------------------------------------------------------------------------------------
-// k_chain_mid (round 3): a dependent chain of n steps on 9..64 ciphertexts — too many for k_trace_tail's one group per XCD,
-// too few to fill the chip with one workgroup per ciphertext (the source default 2^14 has 16 ciphertexts per round, 2^16 has
-// 64: ten / eight alone packer levels and the four products of coordinate 0, each a pair of launches per step before) — as
-// ONE launch with in-kernel hand-offs, by the mechanism of k_trace_tail: the MEMBERS workgroups of a ciphertext sit on one XCD
-// (block b runs on XCD b % 8; checked, not assumed), meet at a counter in that XCD's L2 and read each other's data past
-// their L1; every wait is bounded, a group that cannot meet raises the abort word and the fused chain launch enqueued behind
-// (predicated on it) redoes the chain from the untouched source.
-//   member m of a ciphertext produces LPM = 2*SK / MEMBERS of the 2*SK un-normalised output limb polynomials (all forward
-//     transforms of the input + MAC + one inverse transform per polynomial), stores them as doubles;       hand-off A
-//   normalisation phase: one thread per (column, coefficient), MEMBERS * T threads per ciphertext;          hand-off B
-// Intermediate ciphertexts travel in the one-double form of ks_trace_y: TRACE: Y = ceil(A/2) (the consumer wants rsh1 of the
-// previous output: its digits ARE the digits of Y); EP: A itself (the consumer wants the digits of the previous output).
-// Same sums, same carry chain per coefficient as the fused kernels: bit-identical results.
-//   grid: 256 blocks; XCD x = b % 8, i = b / 8; slot = i / MEMBERS, member = i % MEMBERS; ciphertext = slot * 8 + x
+// k_chain_mid (round 3): a dependent chain of n steps on 9..16 ciphertexts — too many for k_trace_tail's one group per XCD,
+// too few for one workgroup per ciphertext (the source default MAX_ADDR = 2^14 has 16 ciphertexts per round: ten alone packer
+// levels and the four products of coordinate 0, each a pair of launches per step before) — as ONE launch with in-kernel
+// hand-offs, by the mechanism of k_trace_tail: the MEMBERS = 3 * SK workgroups of a ciphertext sit on one XCD (block b runs on
+// XCD b % 8; checked, not assumed), two ciphertexts per XCD, meet at a counter in that XCD's L2 and read each other's data
+// past their L1.
+//   member (r, h): digit r of the input (TRACE: of the mask column, seen through phi_g; EP: of both columns) -> one / two
+//     forward transforms; the two output limb polynomials 2h, 2h+1 of the 2*SK: MAC with the operands of digit r, one
+//     inverse transform each -> a PARTIAL (the sum over r is taken by the normalisation phase);                hand-off A
+//   normalisation phase: one thread per (column, coefficient), MEMBERS * T threads per ciphertext;              hand-off B
+// Intermediate ciphertexts live in a scratch of their own, in the one-double form of ks_trace_y: TRACE: Y = ceil(A/2) (the
+// consumer wants rsh1 of the previous output: its digits ARE the digits of Y); EP: A itself.  Same sums, same carry chain per
+// coefficient as the fused kernels: bit-identical results.  The destination is written by the LAST step only, after the
+// group's last hand-off — so the chain may run in place (read_prepare_write's products on the stored rows).
+// Giving up.  Every wait is bounded.  Each ciphertext's group stands alone: a member that cannot meet the others (not
+// co-resident, wrong placement) POISONS the group's counter (a compare-and-swap from a value below the awaited one: once a
+// barrier has been reached by all, nobody can poison it any more, so the last hand-off is all-or-nothing and the destination
+// is written by every member or by none) and leaves; the last member to leave records whether the group completed, and the
+// fused chain launch enqueued behind redoes exactly the ciphertexts that did not, from the untouched source.
+//   grid: 8 * 2 * MEMBERS blocks; XCD x = b % 8, i = b / 8; slot = i / MEMBERS, member = i % MEMBERS; ciphertext = slot * 8 + x
+//   sync: [ciphertext][32] words: arrivals (| poison), leavers, XCC mask, completed generation;  sync[16 * 32 + 1] = ciphertexts redone
 // ---------------------------------------------------------------------------------------
-constexpr int MID_GROUPS_MAX = 64;
+constexpr unsigned MID_POISON = 0x80000000u;
 struct MidArgs {
-    GlweRef src, buf[2];             // step i writes buf[i & 1] (buf[0] must not be the source; the source is never written)
+    GlweRef src, dst;                // dst may be src
     const double* opnd[CHAIN_MAX];   // TRACE: prepared trace key of step i;  EP: prepared GGSW digit i
     int ginv[CHAIN_MAX];             // TRACE: g_i^-1 mod 2N
     const double* tw;
-    double* big;                     // [ciphertext] x BIG_STRIDE doubles: the un-normalised limb polynomials [col][limb][N]
-    unsigned* sync;                  // [MID_GROUPS_MAX][32] words (arrivals, leavers, XCC mask) + [abort generation, fallbacks taken]
+    double* big;                     // [ciphertext] x (SX * BIG_STRIDE) doubles: partials [col][limb][r][N]
+    double* y;                       // [2][MID_GROUPS_MAX][2][N] doubles: the intermediates, ping-pong by step parity
+    unsigned* sync;
     unsigned seq;                    // generation of this launch (never 0)
     int n, n_ct, gx;                 // steps, ciphertexts, ciphertexts per row of the (x, y) grid the GlweRefs are indexed by
     int rot_mul, rot_base;           // TRACE: the first step reads its input rotated by X^-(rot_base + x * rot_mul)  (write path)
     int give_up_at;                  // test hook: member 1 of ciphertext 0 gives up at this step (-1: never)
 };
-template <bool EP, int SK, int MEMBERS>
+// All members of a group meet at `want` arrivals; false = the group has given up (this workgroup must leave).
+__device__ __forceinline__ bool mid_barrier(unsigned* ctr, unsigned want, int* flag, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
+    __syncthreads();
+    if (tid == 0) {
+        unsigned v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        int ok = -1;
+        for (int spin = 0; spin < TAIL_SPIN_MAX && ok < 0; spin++) {
+            if (v & MID_POISON) ok = 0;
+            else if (v >= want) ok = 1;
+            else v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        while (ok < 0) {   // waited long enough: give up — unless everybody has arrived meanwhile (then nobody may)
+            if (v & MID_POISON) ok = 0;
+            else if (v >= want) ok = 1;
+            else if (__hip_atomic_compare_exchange_strong(ctr, &v, v | MID_POISON, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+template <bool EP, int SK>
 __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int SX = 3, SO = 3, NP = 2 * SK;
-    static_assert(NP % MEMBERS == 0 && MEMBERS <= 32, "members per ciphertext");
-    constexpr int LPM = NP / MEMBERS;          // output limb polynomials per member
-    constexpr int GPX = 32 / MEMBERS;          // ciphertexts per XCD
+    constexpr int SX = 3, SO = 3, NP = 2 * SK, LPM = 2, NX = EP ? 2 : 1;
+    constexpr int MEMBERS = SX * NP / LPM;     // 12 (4-limb operands) or 15 (5-limb trace keys)
+    constexpr int GPX = 2;                     // ciphertexts per XCD
+    static_assert(GPX * MEMBERS <= 32, "members of an XCD's ciphertexts must be co-resident on its 32 CUs");
     const int xcd = (int)blockIdx.x % 8, bi = (int)blockIdx.x / 8;
     const int slot = bi / MEMBERS, m = bi % MEMBERS;
     const int ctg = slot * 8 + xcd;            // ciphertext (group) of this workgroup
     if (slot >= GPX || ctg >= ma.n_ct) return;
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
+    int tid = tid0;
+    const int r = m % SX, h = m / SX;          // input digit; output limb polynomials h * LPM + l
     double* tw = lds;
     double* data = lds + LDS_TW;
-    double* stage0 = data;                     // exchange buffer 0, before the transforms: the mask column (TRACE) in the one-double form
-    double* stage1 = data + 2 * LDS_DATA;      // third buffer, after the forward transforms: the body column (TRACE, members that add it)
+    double* stage0 = data;                     // exchange buffer 0, before the forward transform: the mask column's digit r (TRACE)
+    double* stage1 = data + 2 * LDS_DATA;      // third buffer (no transform of this kernel uses it): the body column (TRACE)
     int* flag = reinterpret_cast<int*>(lds + LDS_TW + BMAX * LDS_DATA - 2);   // the padding at the very end of the LDS allocation
     unsigned* ctr = ma.sync + ctg * 32;
-    unsigned* abortp = ma.sync + MID_GROUPS_MAX * 32;
     const long cty = (long)(ctg / ma.gx), ctx_ = (long)(ctg % ma.gx);
-    double* bigg = ma.big + (long)ctg * BIG_STRIDE;
+    double* bigg = ma.big + (long)ctg * BIG_STRIDE * SX;
     if (tid == 0) {
         __hip_atomic_fetch_or(ctr + 2, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // performed before this workgroup's first arrival is counted
     }
     load_twiddles(tw, ma.tw, tid);
-    bool needs_body = false;                   // TRACE: does this member produce a polynomial of column 0 with limb index < SX?
+    bool needs_body = false;                   // TRACE: does this member add the body column to one of its partials?
     if constexpr (!EP) {
 #pragma unroll
-        for (int l = 0; l < LPM; l++) { const int pi = m * LPM + l; if (pi / SK == 0 && (SK - 1 - pi % SK) < SX) needs_body = true; }
+        for (int l = 0; l < LPM; l++) { const int pi = h * LPM + l; if (r == 0 && pi / SK == 0 && (SK - 1 - pi % SK) < SX) needs_body = true; }
     }
+    const int32_t* ap = ma.src.p + cty * ma.src.sy + ctx_ * ma.src.sx;
+    int32_t* op = ma.dst.p + cty * ma.dst.sy + ctx_ * ma.dst.sx;
+    const int rho = -(ma.rot_base + (int)ctx_ * ma.rot_mul);         // first TRACE step only
     unsigned epoch = 0;
 #pragma unroll 1
     for (int s = 0; s < ma.n; s++) {
-        const GlweRef rin = (s == 0) ? ma.src : ma.buf[(s - 1) & 1];
-        const GlweRef rout = ma.buf[s & 1];
-        const int32_t* ap = rin.p + cty * rin.sy + ctx_ * rin.sx;
-        int32_t* op = rout.p + cty * rout.sy + ctx_ * rout.sx;
-        const double* yin = reinterpret_cast<const double*>(ap);     // inner steps: [col][N] doubles in the ciphertext's slot
-        double* yout = reinterpret_cast<double*>(op);
+        const double* yin = ma.y + ((long)((s + 1) & 1) * MID_GROUPS_MAX + ctg) * (2 * N);   // [col][N], written by step s - 1
+        double* yout = ma.y + ((long)(s & 1) * MID_GROUPS_MAX + ctg) * (2 * N);
         const bool first = (s == 0), last = (s + 1 == ma.n);
+        tid = tid0;
+        asm volatile("" : "+v"(tid));   // per-step copy the optimiser cannot see through (see k_ext_product_chain)
+        __builtin_assume(tid >= 0 && tid < T);
         const int ginv = EP ? 1 : ma.ginv[s];
-        const int rho = -(ma.rot_base + (int)ctx_ * ma.rot_mul);     // first TRACE step only
         const int sidx0 = (tid * ginv) & (2 * N - 1), sstep = (T * ginv) & (2 * N - 1);
         // the one-double form of column `col` at natural coefficient i: A (EP) or Y = ceil(A/2) (TRACE)
         auto one_double = [&](int col, int i) -> double {
@@ -1744,88 +1783,66 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             a = neg ? -a : a;
             return __builtin_floor(__builtin_fma(a, 0.5, 0.5));
         };
-        // the operands of the member's first polynomial are requested before anything else: they arrive during phase 1
-        OpRegs g[SX];
-        auto fetch = [&](int l, int cin) {
-            const int pi = m * LPM + l, co = pi / SK, j = SK - 1 - pi % SK;
-#pragma unroll
-            for (int r = 0; r < SX; r++)
-                load_ops(g[r], ma.opnd[s] + (long)(((EP ? (2 * r + cin) : r) * SK + j) * 2 + co) * N, tid);
+        // digit r of c (c = the one-double form): digits leave from the least significant end
+        auto digit_r = [&](double c) -> double {
+            double d = take_digit(c);
+            if (r < 2) d = take_digit(c);
+            if (r < 1) d = c;
+            return d;
         };
-        // (requested after phase 1: held across the batched forward transforms the 48 operand registers spill)
-        // ---- phase 1: inputs; their digits (TRACE: seen through phi_g); forward transforms
-        double xh[EP ? 2 * SX : SX][E];
-        double vb[E];                          // TRACE: the body column at this thread's natural coefficients (members that add it)
+        OpRegs g[NX];
+        auto fetch = [&](int l) {
+            const int pi = h * LPM + l, co = pi / SK, j = SK - 1 - pi % SK;
+#pragma unroll
+            for (int cin = 0; cin < NX; cin++)
+                load_ops(g[cin], ma.opnd[s] + (long)(((EP ? (2 * r + cin) : r) * SK + j) * 2 + co) * N, tid);
+        };
+        fetch(0);                              // arrives during phase 1
+        // ---- phase 1: digit r of the input (TRACE: of the mask column through phi_g), forward transform(s)
+        double x[NX][E];
         if constexpr (EP) {
-            // one column at a time: the second column's digits are loaded after the first one's transforms
 #pragma unroll
             for (int col = 0; col < 2; col++) {
                 if (first) {                   // the limbs as they are stored (they need not be normalised: a rotation's negation leaves +2^16)
 #pragma unroll
-                    for (int k = 0; k < E; k++)
-#pragma unroll
-                        for (int q = 0; q < SX; q++) xh[col * SX + q][k] = (double)ap[glwe_off(q, col) + tid + T * k];
+                    for (int k = 0; k < E; k++) x[col][k] = (double)ap[glwe_off(r, col) + tid + T * k];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < E; k++) {
-                        double c = one_double(col, tid + T * k);
-                        xh[col * SX + 2][k] = take_digit(c); xh[col * SX + 1][k] = take_digit(c); xh[col * SX][k] = c;
-                    }
+                    for (int k = 0; k < E; k++) x[col][k] = digit_r(one_double(col, tid + T * k));
                 }
-                fwd_all<SX>(*reinterpret_cast<double(*)[SX][E]>(&xh[col * SX]), tw, data, tid);
             }
-            fetch(0, 0);
         } else {
-            lds_barrier();                     // the previous step's last inverse transform may still be read across waves in buffer 0
 #pragma unroll
-            for (int k = 0; k < E; k++) stage0[tid + T * k] = one_double(1, tid + T * k);
+            for (int k = 0; k < E; k++) stage0[tid + T * k] = digit_r(one_double(1, tid + T * k));
             if (needs_body) {
 #pragma unroll
-                for (int k = 0; k < E; k++) vb[k] = one_double(0, tid + T * k);
+                for (int k = 0; k < E; k++) stage1[tid + T * k] = one_double(0, tid + T * k);
             }
             __syncthreads();
             int sidx = sidx0;
 #pragma unroll
             for (int k = 0; k < E; k++) {
-                const bool ng = sidx >= N;
-                double c = stage0[sidx & (N - 1)];
-                const double d2 = take_digit(c), d1 = take_digit(c);
-                xh[2][k] = ng ? -d2 : d2; xh[1][k] = ng ? -d1 : d1; xh[0][k] = ng ? -c : c;
+                const double d = stage0[sidx & (N - 1)];
+                x[0][k] = (sidx >= N) ? -d : d;
                 sidx = (sidx + sstep) & (2 * N - 1);
             }
-            fwd_all<SX>(*reinterpret_cast<double(*)[SX][E]>(&xh[0]), tw, data, tid);   // starts with a barrier: every gather is done
-            fetch(0, 0);
-            if (needs_body) {                  // the body column, staged for the gathers below (the forward transforms used all three buffers)
-                lds_barrier();
-#pragma unroll
-                for (int k = 0; k < E; k++) stage1[tid + T * k] = vb[k];
-                // published by the barrier at the start of the first inverse transform
-            }
         }
-        // ---- phase 2: this member's output limb polynomials, un-normalised
-#pragma unroll 1
+        ntt_fwd<NX>(x, tw, data, tid);         // starts with a barrier: every gather of the staged digits is done
+        // ---- phase 2: this member's partials of its two output limb polynomials
+#pragma unroll
         for (int l = 0; l < LPM; l++) {
-            const int pi = m * LPM + l, co = pi / SK, j = SK - 1 - pi % SK;
+            const int pi = h * LPM + l, co = pi / SK, j = SK - 1 - pi % SK;
             double acc[1][E];
 #pragma unroll
             for (int k = 0; k < E; k++) acc[0][k] = 0.0;
-            if constexpr (EP) {
 #pragma unroll
-                for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
-                __builtin_amdgcn_sched_barrier(0);
-                fetch(l, 1);                                         // column_in 1 (one exposed round trip per polynomial)
-#pragma unroll
-                for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[SX + r], g[r]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (l + 1 < LPM) fetch(l + 1, 0);                    // the next polynomial's operands arrive during the inverse transform
-                ntt_inv<1, true, true>(acc, tw, data, tid);          // six MAC terms: with the initial reduction
-            } else {
-#pragma unroll
-                for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (l + 1 < LPM) fetch(l + 1, 0);
-                ntt_inv<1, true, false>(acc, tw, data, tid);         // three MAC terms: none
-                if (co == 0 && j < SX) {       // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
+            for (int cin = 0; cin < NX; cin++) mac_regs(acc[0], x[cin], g[cin]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (l + 1 < LPM) fetch(l + 1);     // arrives during the inverse transform
+            // at most two MAC terms: no initial reduction; buffer l: the previous transform in it was a forward one (fenced inside) or none
+            ntt_inv<1, false, false>(acc, tw, data + l * LDS_DATA, tid);
+            if constexpr (!EP) {
+                if (r == 0 && co == 0 && j < SX) {   // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
                     int sidx = sidx0;
 #pragma unroll
                     for (int k = 0; k < E; k++) {
@@ -1838,37 +1855,53 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
                     }
                 }
             }
-            double* bgp = bigg + (long)(co * SK + j) * N;
+            double* bgp = bigg + (long)((co * SK + j) * SX + r) * N;
 #pragma unroll
             for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
         }
-        if (ma.give_up_at == s && ctg == 0 && m == 1 % MEMBERS) {
-            if (tid == 0) __hip_atomic_store(abortp, ma.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ma.give_up_at == s && ctg == 0 && m == 1) {
+            if (tid == 0) __hip_atomic_fetch_or(ctr, MID_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
-        if (!tail_barrier(ctr, abortp, ma.seq, (++epoch) * MEMBERS, flag, s == 0, tid)) break;
-        // ---- normalisation phase: one thread per (column, coefficient): same arithmetic as the emit step of the fused kernels
-#pragma unroll 1
-        for (int item = m * T + tid; item < 2 * N; item += MEMBERS * T) {
-            const int nco = item / N, i = item % N;
-            const double* bgp = bigg + (long)nco * SK * N + i;
-            double cq = 0.0;                   // TRACE: the running quotient of Y at this coefficient (post-step operand)
-            if constexpr (!EP) {
-                if (!first) cq = ld_l2(yin + (long)nco * N + i);
-                else {
-                    int src; bool neg;
-                    rot_src(i, rho, src, neg);
-                    double a = __builtin_fma(__builtin_fma((double)ap[glwe_off(0, nco) + src], TWO_B, (double)ap[glwe_off(1, nco) + src]), TWO_B,
-                                             (double)ap[glwe_off(2, nco) + src]);
-                    a = neg ? -a : a;
-                    cq = __builtin_floor(__builtin_fma(a, 0.5, 0.5));
-                }
+        if (!mid_barrier(ctr, (++epoch) * MEMBERS, flag, tid)) break;
+        if (first) {                           // placement: all members of the group on one XCD (they all read the same mask: all stay or all leave)
+            if (__builtin_popcount(__hip_atomic_load(ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 1) {
+                if (tid == 0) __hip_atomic_fetch_or(ctr, MID_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
             }
+        }
+        // ---- normalisation phase: one thread per (column, coefficient): same arithmetic as the emit step of the fused kernels.
+        // 2N items over MEMBERS * T threads: one or two per thread — both items' loads are issued before either is used (the
+        // phase is one L2 round trip long, not two)
+        constexpr int NIT = (2 * N + MEMBERS * T - 1) / (MEMBERS * T);
+        static_assert(NIT == 2, "two items per thread at most");
+        double v_[NIT][SK], cqv[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; u++) {
+            const int item = m * T + tid + u * MEMBERS * T;
+            const bool on = item < 2 * N;
+            const int nco = on ? item / N : 0, i = on ? item % N : 0;
+            const double* bgp = bigg + (long)nco * SK * SX * N + i;
+#pragma unroll
+            for (int q = 0; q < SK; q++) {
+                v_[u][q] = ld_l2(bgp + (long)(q * SX) * N);
+#pragma unroll
+                for (int w = 1; w < SX; w++) v_[u][q] += ld_l2(bgp + (long)(q * SX + w) * N);   // exact: integers below 2^50
+            }
+            cqv[u] = 0.0;                      // TRACE: Y of the step's input at this coefficient (the `+ x` of the trace step)
+            if constexpr (!EP) cqv[u] = one_double(nco, i);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; u++) {
+            const int item = m * T + tid + u * MEMBERS * T;
+            if (item >= 2 * N) break;
+            const int nco = item / N, i = item % N;
+            double cq = cqv[u];
             double carry = 0.0, ad = 0.0;
             int dig[SO];
 #pragma unroll
             for (int q = SK - 1; q >= 0; q--) {
-                double v = ld_l2(bgp + (long)q * N);
+                double v = v_[u][q];
                 if constexpr (!EP) {
                     if (q < SX) v += (q > 0) ? take_digit(cq) : cq;
                 }
@@ -1888,13 +1921,16 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
                 yout[(long)nco * N + i] = EP ? ad : __builtin_floor(__builtin_fma(ad, 0.5, 0.5));
             }
         }
-        if (!last && !tail_barrier(ctr, abortp, ma.seq, (++epoch) * MEMBERS, flag, false, tid)) break;
+        if (!last && !mid_barrier(ctr, (++epoch) * MEMBERS, flag, tid)) break;
     }
-    // the last workgroup of the group to leave rewinds the group's words for the next launch (as k_trace_tail)
+    // the last workgroup of the group to leave (every one passes here exactly once, given up or not) records whether the
+    // group completed and rewinds the group's words for the next launch: nobody can still be waiting on them
     __syncthreads();
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == (unsigned)(MEMBERS - 1)) {
+            const unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr + 3, (v & MID_POISON) ? 0u : ma.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ctr + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -117,59 +117,54 @@ void run_chain(fheram_ctx* c, int n, GlweRef src, GlweRef dst, GlweRef tmp, int 
         cur = out;
     }
 }
-// Dependent chains on 9..64 ciphertexts (MAX_ADDR = 2^13 .. 2^16: the alone packer levels, the products of coordinate 0,
-// write_mid_step's traces): ONE launch with in-kernel hand-offs (k_chain_mid), followed by the fused chain launch that only
-// runs if that one gave up.  members = workgroups per ciphertext (0: not applicable).
-int mid_members(const fheram_ctx* c, int n, int gx, int gy, int sk) {
+// Dependent chains on 9..16 ciphertexts (MAX_ADDR = 2^13, 2^14: the alone packer levels, the products of coordinate 0,
+// write_mid_step's traces): ONE launch with in-kernel hand-offs (k_chain_mid), followed by the fused chain launch that redoes
+// the ciphertexts whose group gave up (normally none).
+bool use_mid(const fheram_ctx* c, int n, int gx, int gy) {
     const long batch = (long)gx * gy;
-    if (!c->mid || !c->limb_split || n < 2 || n > CHAIN_MAX || batch <= TAIL_GROUPS || c->cus < 256 || (c->use_graph && !c->profile)) return 0;
-    if (sk == 4) return batch <= 32 ? 8 : (batch <= 64 ? 4 : 0);
-    if (sk == 5) return batch <= 24 ? 10 : (batch <= 48 ? 5 : 0);
-    return 0;
+    return c->mid && c->limb_split && n >= 2 && n <= CHAIN_MAX && batch > TAIL_GROUPS && batch <= MID_GROUPS_MAX &&
+           c->cus >= TAIL_GROUPS * 32 &&     // the whole chip (8 XCDs x 32 CUs)
+           !(c->use_graph && !c->profile);   // a captured launch would replay its generation number
 }
-unsigned* mid_sync_of(fheram_ctx* c) { return c->d_mid_sync[c->cur == c->stream2 ? 1 : 0]; }
 template <bool EP>
-void fill_mid(fheram_ctx* c, MidArgs& ma, GlweRef src, const GlweRef (&b)[2], int n, int gx, int gy) {
-    ma.src = src; ma.buf[0] = b[0]; ma.buf[1] = b[1]; ma.tw = c->d_tw; ma.big = big_of(c); ma.sync = mid_sync_of(c);
+void fill_mid(fheram_ctx* c, MidArgs& ma, GlweRef src, GlweRef dst, int n, int gx, int gy) {
+    const int side = c->cur == c->stream2 ? 1 : 0;
+    ma.src = src; ma.dst = dst; ma.tw = c->d_tw; ma.big = big_of(c); ma.sync = c->d_mid_sync[side]; ma.y = c->d_mid_y[side];
     if (++c->mid_seq == 0) ++c->mid_seq;
     c->mid_launches++;
     ma.seq = c->mid_seq; ma.n = n; ma.n_ct = gx * gy; ma.gx = gx; ma.rot_mul = 0; ma.rot_base = 0;
     ma.give_up_at = c->mid_test ? n - 2 : -1;
 }
-// src must survive the launch (its fallback restarts from it): b[0], b[1] != src
-void launch_mid_trace(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy, int rot_mul, int rot_base, int members) {
+// b: the buffers of the fallback chain (step i writes b[i & 1]; b[0] != src); the result lands in b[(n - 1) & 1], which may be src
+void launch_mid_trace(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy, int rot_mul, int rot_base) {
     ProfScope ps(c, "keyswitch", (uint64_t)gx * gy, n);
     ProfScope pm(c, "keyswitch_mid_launch", (uint64_t)gx * gy * n, 1);
     MidArgs ma;
-    fill_mid<false>(c, ma, src, b, n, gx, gy);
+    fill_mid<false>(c, ma, src, b[(n - 1) & 1], n, gx, gy);
     ma.rot_mul = rot_mul; ma.rot_base = rot_base;
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
-    ca.pred = ma.sync + MID_GROUPS_MAX * 32; ca.pred_seq = ma.seq; ca.host_count = nullptr;
+    ca.done = ma.sync; ca.done_seq = ma.seq;
     for (int i = 0; i < n; i++) { ma.opnd[i] = ca.key[i] = trace_key(c, start + i); ma.ginv[i] = ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
-    const dim3 grid(256);
     if (c->s_evk == 5) {
-        if (members == 10) hipLaunchKernelGGL((k_chain_mid<false, 5, 10>), grid, dim3(T), LDS_BYTES, c->cur, ma);
-        else hipLaunchKernelGGL((k_chain_mid<false, 5, 5>), grid, dim3(T), LDS_BYTES, c->cur, ma);
+        hipLaunchKernelGGL((k_chain_mid<false, 5>), dim3(8 * 2 * 15), dim3(T), LDS_BYTES, c->cur, ma);
         hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     } else {
-        if (members == 8) hipLaunchKernelGGL((k_chain_mid<false, 4, 8>), grid, dim3(T), LDS_BYTES, c->cur, ma);
-        else hipLaunchKernelGGL((k_chain_mid<false, 4, 4>), grid, dim3(T), LDS_BYTES, c->cur, ma);
+        hipLaunchKernelGGL((k_chain_mid<false, 4>), dim3(8 * 2 * 12), dim3(T), LDS_BYTES, c->cur, ma);
         hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }
 }
-void launch_mid_ep(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const double* prep, int d, int gx, int gy, int members) {
+void launch_mid_ep(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const double* prep, int d, int gx, int gy) {
     ProfScope ps(c, "ext_product", (uint64_t)gx * gy, d);
     ProfScope pm(c, "ext_product_mid_launch", (uint64_t)gx * gy * d, 1);
     MidArgs ma;
-    fill_mid<true>(c, ma, src, b, d, gx, gy);
+    fill_mid<true>(c, ma, src, b[(d - 1) & 1], d, gx, gy);
     EpChainArgs ca;
     ca.src = src; ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.tw = c->d_tw; ca.n = d;
-    ca.pred = ma.sync + MID_GROUPS_MAX * 32; ca.pred_seq = ma.seq;
+    ca.done = ma.sync; ca.done_seq = ma.seq;
     for (int i = 0; i < d; i++) { ma.opnd[i] = ca.ggsw[i] = prep + (size_t)i * fheram_ctx::GGSW; ma.ginv[i] = 1; }
-    if (members == 8) hipLaunchKernelGGL((k_chain_mid<true, 4, 8>), dim3(256), dim3(T), LDS_BYTES, c->cur, ma);
-    else hipLaunchKernelGGL((k_chain_mid<true, 4, 4>), dim3(256), dim3(T), LDS_BYTES, c->cur, ma);
+    hipLaunchKernelGGL((k_chain_mid<true, 4>), dim3(8 * 2 * 12), dim3(T), LDS_BYTES, c->cur, ma);
     hipLaunchKernelGGL((k_ext_product_chain<3, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
 }
 // A dependent chain of n fused steps on the same ciphertexts runs as ONE launch when the batch is large enough
@@ -196,9 +191,9 @@ void launch_ep_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const do
 // CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): d external products.
 void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, const double* prep, int d, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
-    if (const int mm = mid_members(c, d, gx, gy, 4)) {
-        GlweRef b[2];   // out of place only (an in-place product — read_prepare_write — keeps the launch-per-step path below)
-        if (chain_bufs(d, src, dst, tmp, b) && !same(b[1], src)) { launch_mid_ep(c, src, b, prep, d, gx, gy, mm); return; }
+    if (use_mid(c, d, gx, gy)) {
+        GlweRef b[2];   // in place too (read_prepare_write): only the last step writes the destination
+        if (chain_bufs(d, src, dst, tmp, b)) { launch_mid_ep(c, src, b, prep, d, gx, gy); return; }
     }
     if (use_chain(c, d, gx, gy, 4) && !use_fine_split(c, gx, gy, 2 * 4 * 2 * 3)) {
         GlweRef b[2];
@@ -274,9 +269,9 @@ void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start
         GlweRef b[2];
         if (chain_bufs(n, src, dst, tmp, b) && !same(b[1], src)) { launch_trace_tail(c, src, b, start, n, gx, gy); return; }
     }
-    if (const int mm = mid_members(c, n, gx, gy, c->s_evk)) {
-        GlweRef b[2];   // out of place only: the source must survive the launch
-        if (chain_bufs(n, src, dst, tmp, b) && !same(b[1], src)) { launch_mid_trace(c, src, b, start, n, gx, gy, rot_mul, rot_base, mm); return; }
+    if (use_mid(c, n, gx, gy)) {
+        GlweRef b[2];
+        if (chain_bufs(n, src, dst, tmp, b)) { launch_mid_trace(c, src, b, start, n, gx, gy, rot_mul, rot_base); return; }
     }
     if (use_chain(c, n, gx, gy, c->s_evk) && !use_fine_split(c, gx, gy, 2 * c->s_evk * 3)) {
         GlweRef b[2];
@@ -312,13 +307,21 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
         trace_steps(c, ref(src, sy, sx), ref(A, sy, sx), ref(B, sy, sx), 0, n_alone, (int)count, gy);
         cur = A;
     } else
-    if (count > 0 && P0 && P0 != cur && mid_members(c, n_alone, (int)count, gy, c->s_evk)) {
-        // mid-sized batch: one launch with in-kernel hand-offs; its source must survive, so it ping-pongs between the arena the
-        // leaves are not in and a third one (P0)
+    if (count > 0 && use_tail(c, n_alone, (int)count, gy) && (other(other(cur)) != cur || (P0 && P0 != cur))) {
+        // at most 8 leaves (MAX_ADDR = 2^13): the single-launch trace chain of the tail.  Its source must survive the launch
+        // (the fallback restarts from it): when the leaves sit in one of the arenas the third one (P0) stands in for it
         int32_t* b0 = other(cur);
-        const GlweRef b[2] = {ref(b0, sy, sx), ref(P0, sy, sx)};
-        launch_mid_trace(c, ref(cur, sy, sx), b, 0, n_alone, (int)count, gy, 0, 0, mid_members(c, n_alone, (int)count, gy, c->s_evk));
-        cur = ((n_alone - 1) & 1) ? P0 : b0;
+        int32_t* b1 = other(b0) != cur ? other(b0) : P0;
+        const GlweRef b[2] = {ref(b0, sy, sx), ref(b1, sy, sx)};
+        launch_trace_tail(c, ref(cur, sy, sx), b, 0, n_alone, (int)count, gy);
+        cur = ((n_alone - 1) & 1) ? b1 : b0;
+    } else
+    if (count > 0 && use_mid(c, n_alone, (int)count, gy)) {
+        int32_t* b0 = other(cur);
+        int32_t* b1 = other(b0);
+        const GlweRef b[2] = {ref(b0, sy, sx), ref(b1, sy, sx)};
+        launch_mid_trace(c, ref(cur, sy, sx), b, 0, n_alone, (int)count, gy, 0, 0);
+        cur = ((n_alone - 1) & 1) ? b1 : b0;
     } else
     if (count > 0 && use_chain(c, n_alone, (int)count, gy, c->s_evk) && !use_fine_split(c, (int)count, gy, 2 * c->s_evk * 3)) {
         int32_t* b0 = other(cur);
