@@ -1205,13 +1205,11 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
     double* tw = lds;
     double* data = lds + LDS_TW;
     int* mstage = reinterpret_cast<int*>(data);
-    int* bstage = mstage + N;
     int* flag = reinterpret_cast<int*>(data + 2 * LDS_DATA);   // the third exchange buffer is not used here
     unsigned* ctr = ta.sync + g * 32;
     unsigned* abortp = ta.sync + TAIL_GROUPS * 32;
     const int r = m % SX, zz = m / SX;
     const int j = SK - 1 - zz % SK, co = zz / SK;
-    const bool adds_body = (r == 0 && co == 0 && j < SX);
     const long ct = (long)(g / ta.gx);
     const long cx = (long)(g % ta.gx);
     double* bigg = ta.big + (long)g * BIG_STRIDE * SX;
@@ -1236,22 +1234,14 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
         // ---- fine phase: x = rsh1(a); partial[co][j][r] = INTT(NTT(phi_g(x.mask limb r)) . K[r][j][co]) (+ phi_g(x.body limb j))
         // staging: thread t brings coefficients 8t .. 8t+7 (natural order) of the limb polynomials it needs
         if (stepped) {
-            int v[E], w[E];
+            int v[E];
 #pragma unroll
             for (int q = 0; q < E / 2; q++) ld_l2_pair(ap + glwe_off(r, 1) + E * tid + 2 * q, v[2 * q], v[2 * q + 1]);
-            if (adds_body) {
-#pragma unroll
-                for (int q = 0; q < E / 2; q++) ld_l2_pair(ap + glwe_off(j, 0) + E * tid + 2 * q, w[2 * q], w[2 * q + 1]);
-            }
 #pragma unroll
             for (int k = 0; k < E; k++) mstage[E * tid + k] = v[k];
-            if (adds_body) {
-#pragma unroll
-                for (int k = 0; k < E; k++) bstage[E * tid + k] = w[k];
-            }
         } else {
             // the source was written by an earlier launch: ordinary (16-byte) loads
-            int rm[SX][E], rb[SX][E];
+            int rm[SX][E];
 #pragma unroll
             for (int q = 0; q < SX; q++)
 #pragma unroll
@@ -1259,15 +1249,6 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
                     const int4 v4 = *reinterpret_cast<const int4*>(ap + glwe_off(q, 1) + E * tid + 4 * h);
                     rm[q][4 * h] = v4.x; rm[q][4 * h + 1] = v4.y; rm[q][4 * h + 2] = v4.z; rm[q][4 * h + 3] = v4.w;
                 }
-            if (adds_body) {
-#pragma unroll
-                for (int q = 0; q < SX; q++)
-#pragma unroll
-                    for (int h = 0; h < E / 4; h++) {
-                        const int4 v4 = *reinterpret_cast<const int4*>(ap + glwe_off(q, 0) + E * tid + 4 * h);
-                        rb[q][4 * h] = v4.x; rb[q][4 * h + 1] = v4.y; rb[q][4 * h + 2] = v4.z; rb[q][4 * h + 3] = v4.w;
-                    }
-            }
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 int xi[SX], xm[SX];
@@ -1276,28 +1257,16 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
                 rsh1_coeff<SX>(xi, xm);
                 mstage[E * tid + k] = sel_limb(xm, r);
             }
-            if (adds_body) {
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    int xi[SX], xb[SX];
-#pragma unroll
-                    for (int q = 0; q < SX; q++) xi[q] = rb[q][k];
-                    rsh1_coeff<SX>(xi, xb);
-                    bstage[E * tid + k] = sel_limb(xb, j);
-                }
-            }
         }
         __syncthreads();
         TSTAMP(1);
         double x[1][E];
-        int bodyv[E];
         {
             int sidx = (tid * ginv) & (2 * N - 1);
             const int sstep = (T * ginv) & (2 * N - 1);
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 x[0][k] = (double)cneg(mstage[sidx & (N - 1)], sidx >= N);
-                bodyv[k] = adds_body ? cneg(bstage[sidx & (N - 1)], sidx >= N) : 0;
                 sidx = (sidx + sstep) & (2 * N - 1);
             }
         }
@@ -1313,7 +1282,7 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
         {
             double* bgp = bigg + (long)((co * SK + j) * SX + r) * N;
 #pragma unroll
-            for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k] + (double)bodyv[k];
+            for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
         }
         if (ta.give_up_at == s && g == 0 && m == 5) {
             if (tid == 0) __hip_atomic_store(abortp, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1337,18 +1306,25 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
             int raw[SX], xa[SX];
 #pragma unroll
             for (int q = 0; q < SX; q++) raw[q] = ld_l2(ap + glwe_off(q, nco) + i);
+            // vec_znx_big_add_small_inplace of the body column seen through phi_g (column 0 only): it joins the sums here, where
+            // every member has the same share of it, instead of lengthening the fine phase of the three members that owned it
+            const int si = (i * ginv) & (2 * N - 1);
+            int braw[SX], xb[SX];
+#pragma unroll
+            for (int q = 0; q < SX; q++) braw[q] = (nco == 0) ? ld_l2(ap + glwe_off(q, 0) + (si & (N - 1))) : 0;
             if (stepped) {
 #pragma unroll
-                for (int q = 0; q < SX; q++) xa[q] = raw[q];
+                for (int q = 0; q < SX; q++) { xa[q] = raw[q]; xb[q] = braw[q]; }
             } else {
                 rsh1_coeff<SX>(raw, xa);
+                rsh1_coeff<SX>(braw, xb);
             }
             double carry = 0.0;
             int d[SO], y[SO];
 #pragma unroll
             for (int q = SK - 1; q >= 0; q--) {
                 double v = v_[q];
-                if (q < SX) v += (double)xa[q < SX ? q : 0];
+                if (q < SX) v += (double)xa[q < SX ? q : 0] + (double)cneg(xb[q < SX ? q : 0], si >= N);
                 v += carry;
                 const double cy = carry_of(v);
                 carry = cy;
@@ -1743,7 +1719,6 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
     double* tw = lds;
     double* data = lds + LDS_TW;
     double* stage0 = data;                     // exchange buffer 0, before the forward transform: the mask column's digit r (TRACE)
-    double* stage1 = data + 2 * LDS_DATA;      // third buffer (no transform of this kernel uses it): the body column (TRACE)
     int* flag = reinterpret_cast<int*>(lds + LDS_TW + BMAX * LDS_DATA - 2);   // the padding at the very end of the LDS allocation
     unsigned* ctr = ma.sync + ctg * 32;
     const long cty = (long)(ctg / ma.gx), ctx_ = (long)(ctg % ma.gx);
@@ -1753,11 +1728,6 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // performed before this workgroup's first arrival is counted
     }
     load_twiddles(tw, ma.tw, tid);
-    bool needs_body = false;                   // TRACE: does this member add the body column to one of its partials?
-    if constexpr (!EP) {
-#pragma unroll
-        for (int l = 0; l < LPM; l++) { const int pi = h * LPM + l; if (r == 0 && pi / SK == 0 && (SK - 1 - pi % SK) < SX) needs_body = true; }
-    }
     const int32_t* ap = ma.src.p + cty * ma.src.sy + ctx_ * ma.src.sx;
     int32_t* op = ma.dst.p + cty * ma.dst.sy + ctx_ * ma.dst.sx;
     const int rho = -(ma.rot_base + (int)ctx_ * ma.rot_mul);         // first TRACE step only
@@ -1814,10 +1784,6 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
         } else {
 #pragma unroll
             for (int k = 0; k < E; k++) stage0[tid + T * k] = digit_r(one_double(1, tid + T * k));
-            if (needs_body) {
-#pragma unroll
-                for (int k = 0; k < E; k++) stage1[tid + T * k] = one_double(0, tid + T * k);
-            }
             __syncthreads();
             int sidx = sidx0;
 #pragma unroll
@@ -1841,20 +1807,6 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             if (l + 1 < LPM) fetch(l + 1);     // arrives during the inverse transform
             // at most two MAC terms: no initial reduction; buffer l: the previous transform in it was a forward one (fenced inside) or none
             ntt_inv<1, false, false>(acc, tw, data + l * LDS_DATA, tid);
-            if constexpr (!EP) {
-                if (r == 0 && co == 0 && j < SX) {   // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
-                    int sidx = sidx0;
-#pragma unroll
-                    for (int k = 0; k < E; k++) {
-                        double c = stage1[sidx & (N - 1)];
-                        double d = take_digit(c);
-                        if (j <= 1) d = take_digit(c);
-                        if (j == 0) d = c;
-                        acc[0][k] += (sidx >= N) ? -d : d;
-                        sidx = (sidx + sstep) & (2 * N - 1);
-                    }
-                }
-            }
             double* bgp = bigg + (long)((co * SK + j) * SX + r) * N;
 #pragma unroll
             for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
@@ -1875,7 +1827,7 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
         // phase is one L2 round trip long, not two)
         constexpr int NIT = (2 * N + MEMBERS * T - 1) / (MEMBERS * T);
         static_assert(NIT == 2, "two items per thread at most");
-        double v_[NIT][SK], cqv[NIT];
+        double v_[NIT][SK], cqv[NIT], cbv[NIT];
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
             const int item = m * T + tid + u * MEMBERS * T;
@@ -1889,21 +1841,31 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
                 for (int w = 1; w < SX; w++) v_[u][q] += ld_l2(bgp + (long)(q * SX + w) * N);   // exact: integers below 2^50
             }
             cqv[u] = 0.0;                      // TRACE: Y of the step's input at this coefficient (the `+ x` of the trace step)
-            if constexpr (!EP) cqv[u] = one_double(nco, i);
+            cbv[u] = 0.0;                      // TRACE, body column: Y of the input's body where phi_g takes this coefficient from
+            if constexpr (!EP) {
+                cqv[u] = one_double(nco, i);
+                if (nco == 0) cbv[u] = one_double(0, (i * ginv) & (N - 1));
+            }
         }
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
             const int item = m * T + tid + u * MEMBERS * T;
             if (item >= 2 * N) break;
             const int nco = item / N, i = item % N;
-            double cq = cqv[u];
+            double cq = cqv[u], cb = cbv[u];
+            const bool ngb = ((i * ginv) & (2 * N - 1)) >= N;   // phi_g: X^N = -1
             double carry = 0.0, ad = 0.0;
             int dig[SO];
 #pragma unroll
             for (int q = SK - 1; q >= 0; q--) {
                 double v = v_[u][q];
                 if constexpr (!EP) {
-                    if (q < SX) v += (q > 0) ? take_digit(cq) : cq;
+                    if (q < SX) {
+                        v += (q > 0) ? take_digit(cq) : cq;
+                        // vec_znx_big_add_small_inplace of body limb q, seen through phi_g (column 0 only: cb = 0 otherwise)
+                        const double db = (q > 0) ? take_digit(cb) : cb;
+                        v += ngb ? -db : db;
+                    }
                 }
                 v += carry;
                 const double cy = carry_of(v);
