@@ -134,14 +134,14 @@ struct fheram_ctx {
     unsigned tail_fb_mark = 0;
     uint64_t tail_launch_mark = 0;
     unsigned* d_tail_sync = nullptr;   // [8 groups][32] + abort generation, fallbacks taken
-    //  mid: dependent chains on 9..16 ciphertexts as ONE launch with in-kernel hand-offs (k_chain_mid); FHERAM_MID=0: launch
+    //  mid: dependent chains on 9..64 ciphertexts as ONE launch with in-kernel hand-offs (k_chain_mid); FHERAM_MID=0: launch
     //       pairs per step as before; FHERAM_MID=2: test hook, every launch gives up late.  One sync block per stream.
-    int mid = 1;
+    int mid = 2;
     int mid_test = 0;
     unsigned mid_seq = 0;
     uint64_t mid_launches = 0;
-    unsigned* d_mid_sync[2] = {nullptr, nullptr};   // [16 groups][32] + [_, ciphertexts redone]: main / side stream
-    double* d_mid_y[2] = {nullptr, nullptr};        // [2][16 groups][2][N] doubles: the chain's intermediates in the one-double form
+    unsigned* d_mid_sync[2] = {nullptr, nullptr};   // [64 groups][32] + [_, ciphertexts redone]: main / side stream
+    double* d_mid_y[2] = {nullptr, nullptr};        // [2][64 groups][2][N] doubles: the chain's intermediates in the one-double form
     //  inv_id[ci]: d_prep_inv holds the prepared INVERSE digits of coordinate ci of the address with that id
     //              (CoordinatePrepared::prepare_inv, ram.rs:260-271,278-289): read_prepare_write — which is told the
     //              address the write will use — starts them on the (low-priority) side stream next to its trace chain,

@@ -117,7 +117,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->tail_xoff = ((serial++ + (int)getpid()) & 1) * (TAIL_GROUPS / 2);
         c->tail_test = (tl && tl[0] == '2') ? 1 : ((tl && tl[0] == '3') ? 2 : 0);
         const char* md = getenv("FHERAM_MID");
-        c->mid = (md && md[0] == '0') ? 0 : 1;
+        c->mid = (md && md[0] == '0') ? 0 : ((md && md[0] == '1') ? 1 : 2);   // 1: the <= 16 ciphertext split only
         c->mid_test = (md && md[0] == '2') ? 1 : 0;
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
@@ -145,7 +145,9 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_keyswitch_chain<3, 4, 3, true>));
     LDSATTR((&k_keyswitch_chain<3, 5, 3, true>));
     LDSATTR((&k_trace_tail<3, 4, 3>));
-    LDSATTR((&k_chain_mid<false, 4>)); LDSATTR((&k_chain_mid<false, 5>)); LDSATTR((&k_chain_mid<true, 4>));
+    LDSATTR((&k_chain_mid<false, 4, 3, 2>)); LDSATTR((&k_chain_mid<false, 5, 3, 2>)); LDSATTR((&k_chain_mid<true, 4, 3, 2>));
+    LDSATTR((&k_chain_mid<false, 4, 1, 1>)); LDSATTR((&k_chain_mid<false, 5, 1, 1>));
+    LDSATTR((&k_chain_mid<false, 4, 1, 2>)); LDSATTR((&k_chain_mid<false, 5, 1, 2>));
 #define LDSATTR_KS4(M, SX, SK, SO) LDSATTR((&k_keyswitch<M, SX, SK, SO, 1>)); LDSATTR((&k_keyswitch<M, SX, SK, SO, 1, 1>)); LDSATTR((&k_keyswitch_fine<M, SX, SK>))
 #define LDSATTR_KS(M, SX, SK, SO) LDSATTR_KS4(M, SX, SK, SO); LDSATTR((&k_keyswitch<M, SX, SK, SO, 2>))
     LDSATTR_KS(KS_AUTO, 3, 4, 3);

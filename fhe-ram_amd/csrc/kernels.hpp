@@ -412,7 +412,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef r
 // the steps need no device-wide synchronisation — what a sequence of launches pays per step (kernel drain and
 // ramp, kernel arguments, the twiddle table, a cold first load: 5-6 us of 55) is paid once.
 constexpr int CHAIN_MAX = 12;
-constexpr int MID_GROUPS_MAX = 16;   // ciphertexts of a k_chain_mid launch (two per XCD)
+constexpr int MID_GROUPS_MAX = 64;   // ciphertexts of a k_chain_mid launch (at most eight per XCD)
 struct EpChainArgs {
     GlweRef src, buf[2];             // step i writes buf[i & 1] (buf[0] must not be src)
     const double* ggsw[CHAIN_MAX];   // prepared digits
@@ -1644,16 +1644,19 @@ __global__ __launch_bounds__(256) void k_sub_add_norm(GlweRef a, GlweRef b, Glwe
     }
 }
 // ---------------------------------------------------------------------------------------
-// k_chain_mid (round 3): a dependent chain of n steps on 9..16 ciphertexts — too many for k_trace_tail's one group per XCD,
-// too few for one workgroup per ciphertext (the source default MAX_ADDR = 2^14 has 16 ciphertexts per round: ten alone packer
-// levels and the four products of coordinate 0, each a pair of launches per step before) — as ONE launch with in-kernel
-// hand-offs, by the mechanism of k_trace_tail: the MEMBERS = 3 * SK workgroups of a ciphertext sit on one XCD (block b runs on
-// XCD b % 8; checked, not assumed), two ciphertexts per XCD, meet at a counter in that XCD's L2 and read each other's data
-// past their L1.
-//   member (r, h): digit r of the input (TRACE: of the mask column, seen through phi_g; EP: of both columns) -> one / two
-//     forward transforms; the two output limb polynomials 2h, 2h+1 of the 2*SK: MAC with the operands of digit r, one
-//     inverse transform each -> a PARTIAL (the sum over r is taken by the normalisation phase);                hand-off A
-//   normalisation phase: one thread per (column, coefficient), MEMBERS * T threads per ciphertext;              hand-off B
+// k_chain_mid (round 3): a dependent chain of n steps on 9..64 ciphertexts — too many for k_trace_tail's one group per XCD,
+// too few for one workgroup per ciphertext (MAX_ADDR = 2^14, the source default, has 16 ciphertexts per round, 2^15 32, 2^16
+// 64: the alone packer levels and the products of coordinate 0, each a pair of launches per step before) — as ONE launch
+// with in-kernel hand-offs, by the mechanism of k_trace_tail: the MEMBERS workgroups of a ciphertext sit on one XCD (block b
+// runs on XCD b % 8; checked, not assumed), 32 / MEMBERS ciphertexts per XCD, meet at a counter in that XCD's L2 and read
+// each other's data past their L1.  Three splits, by how many ciphertexts must share the chip:
+//   <RS = 3, LPM = 2>  <= 16 ciphertexts: member (r, h): digit r of the input (TRACE: of the mask column, seen through phi_g;
+//     EP: of both columns) -> one / two forward transforms; output limb polynomials 2h, 2h+1 of the 2*SK: MAC with the
+//     operands of digit r, one inverse transform each -> a PARTIAL (the sum over r is taken by the normalisation phase);
+//   <RS = 1, LPM = 1>  <= 32 (TRACE): member h: all three digits (three forward transforms), output limb polynomial h;
+//   <RS = 1, LPM = 2>  <= 64 (TRACE): the same with two output limb polynomials per member;                  hand-off A
+//   normalisation phase: one thread per (column, coefficient), MEMBERS * T threads per ciphertext — the body column of a
+//     trace step (vec_znx_big_add_small) and its `+ x` join the sums here;                                    hand-off B
 // Intermediate ciphertexts live in a scratch of their own, in the one-double form of ks_trace_y: TRACE: Y = ceil(A/2) (the
 // consumer wants rsh1 of the previous output: its digits ARE the digits of Y); EP: A itself.  Same sums, same carry chain per
 // coefficient as the fused kernels: bit-identical results.  The destination is written by the LAST step only, after the
@@ -1663,8 +1666,8 @@ __global__ __launch_bounds__(256) void k_sub_add_norm(GlweRef a, GlweRef b, Glwe
 // barrier has been reached by all, nobody can poison it any more, so the last hand-off is all-or-nothing and the destination
 // is written by every member or by none) and leaves; the last member to leave records whether the group completed, and the
 // fused chain launch enqueued behind redoes exactly the ciphertexts that did not, from the untouched source.
-//   grid: 8 * 2 * MEMBERS blocks; XCD x = b % 8, i = b / 8; slot = i / MEMBERS, member = i % MEMBERS; ciphertext = slot * 8 + x
-//   sync: [ciphertext][32] words: arrivals (| poison), leavers, XCC mask, completed generation;  sync[16 * 32 + 1] = ciphertexts redone
+//   grid: 8 * (32 / MEMBERS) * MEMBERS blocks; XCD x = b % 8, i = b / 8; slot = i / MEMBERS, member = i % MEMBERS; ciphertext = slot * 8 + x
+//   sync: [ciphertext][32] words: arrivals (| poison), leavers, XCC mask, completed generation;  sync[64 * 32 + 1] = ciphertexts redone
 // ---------------------------------------------------------------------------------------
 constexpr unsigned MID_POISON = 0x80000000u;
 struct MidArgs {
@@ -1672,7 +1675,7 @@ struct MidArgs {
     const double* opnd[CHAIN_MAX];   // TRACE: prepared trace key of step i;  EP: prepared GGSW digit i
     int ginv[CHAIN_MAX];             // TRACE: g_i^-1 mod 2N
     const double* tw;
-    double* big;                     // [ciphertext] x (SX * BIG_STRIDE) doubles: partials [col][limb][r][N]
+    double* big;                     // [ciphertext] x (RS * BIG_STRIDE) doubles: partials [col][limb][r][N]
     double* y;                       // [2][MID_GROUPS_MAX][2][N] doubles: the intermediates, ping-pong by step parity
     unsigned* sync;
     unsigned seq;                    // generation of this launch (never 0)
@@ -1702,27 +1705,29 @@ __device__ __forceinline__ bool mid_barrier(unsigned* ctr, unsigned want, int* f
     __syncthreads();
     return *flag != 0;
 }
-template <bool EP, int SK>
+template <bool EP, int SK, int RS, int LPM>
 __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int SX = 3, SO = 3, NP = 2 * SK, LPM = 2, NX = EP ? 2 : 1;
-    constexpr int MEMBERS = SX * NP / LPM;     // 12 (4-limb operands) or 15 (5-limb trace keys)
-    constexpr int GPX = 2;                     // ciphertexts per XCD
-    static_assert(GPX * MEMBERS <= 32, "members of an XCD's ciphertexts must be co-resident on its 32 CUs");
+    constexpr int SX = 3, SO = 3, NP = 2 * SK;
+    static_assert((RS == 1 || RS == SX) && NP % LPM == 0 && (!EP || RS == SX), "member split");
+    constexpr int NX = EP ? 2 : (RS == 1 ? SX : 1);   // forward transforms per member
+    constexpr int MEMBERS = RS * NP / LPM;     // <3,2>: 12 / 15 (4- / 5-limb operands);  <1,1>: 8 / 10;  <1,2>: 4 / 5
+    constexpr int GPX = 32 / MEMBERS;          // ciphertexts per XCD: 2, 4 / 3, 8 / 6
+    static_assert(GPX * MEMBERS <= 32 && 8 * GPX <= MID_GROUPS_MAX, "members of an XCD's ciphertexts must be co-resident on its 32 CUs");
     const int xcd = (int)blockIdx.x % 8, bi = (int)blockIdx.x / 8;
     const int slot = bi / MEMBERS, m = bi % MEMBERS;
     const int ctg = slot * 8 + xcd;            // ciphertext (group) of this workgroup
     if (slot >= GPX || ctg >= ma.n_ct) return;
     const int tid0 = threadIdx.x;
     int tid = tid0;
-    const int r = m % SX, h = m / SX;          // input digit; output limb polynomials h * LPM + l
+    const int r = m % RS, h = m / RS;          // input digit (RS == 1: all three); output limb polynomials h * LPM + l
     double* tw = lds;
     double* data = lds + LDS_TW;
     double* stage0 = data;                     // exchange buffer 0, before the forward transform: the mask column's digit r (TRACE)
     int* flag = reinterpret_cast<int*>(lds + LDS_TW + BMAX * LDS_DATA - 2);   // the padding at the very end of the LDS allocation
     unsigned* ctr = ma.sync + ctg * 32;
     const long cty = (long)(ctg / ma.gx), ctx_ = (long)(ctg % ma.gx);
-    double* bigg = ma.big + (long)ctg * BIG_STRIDE * SX;
+    double* bigg = ma.big + (long)ctg * BIG_STRIDE * RS;
     if (tid == 0) {
         __hip_atomic_fetch_or(ctr + 2, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // performed before this workgroup's first arrival is counted
@@ -1764,8 +1769,8 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
         auto fetch = [&](int l) {
             const int pi = h * LPM + l, co = pi / SK, j = SK - 1 - pi % SK;
 #pragma unroll
-            for (int cin = 0; cin < NX; cin++)
-                load_ops(g[cin], ma.opnd[s] + (long)(((EP ? (2 * r + cin) : r) * SK + j) * 2 + co) * N, tid);
+            for (int cin = 0; cin < NX; cin++)   // operand row: EP: digit r of column cin;  TRACE: digit r (RS == 1: digit cin)
+                load_ops(g[cin], ma.opnd[s] + (long)(((EP ? (2 * r + cin) : (RS == 1 ? cin : r)) * SK + j) * 2 + co) * N, tid);
         };
         fetch(0);                              // arrives during phase 1
         // ---- phase 1: digit r of the input (TRACE: of the mask column through phi_g), forward transform(s)
@@ -1783,17 +1788,22 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < E; k++) stage0[tid + T * k] = digit_r(one_double(1, tid + T * k));
+            for (int k = 0; k < E; k++) { const double c = one_double(1, tid + T * k); stage0[tid + T * k] = (RS == 1) ? c : digit_r(c); }
             __syncthreads();
             int sidx = sidx0;
 #pragma unroll
             for (int k = 0; k < E; k++) {
-                const double d = stage0[sidx & (N - 1)];
-                x[0][k] = (sidx >= N) ? -d : d;
+                double d = stage0[sidx & (N - 1)];
+                const bool ng = sidx >= N;
+                if constexpr (RS == 1) {       // all three digits of the mask column
+                    const double d2 = take_digit(d), d1 = take_digit(d);
+                    x[NX - 1][k] = ng ? -d2 : d2; x[NX > 1 ? 1 : 0][k] = ng ? -d1 : d1;
+                }
+                x[0][k] = ng ? -d : d;
                 sidx = (sidx + sstep) & (2 * N - 1);
             }
         }
-        ntt_fwd<NX>(x, tw, data, tid);         // starts with a barrier: every gather of the staged digits is done
+        fwd_all<NX>(x, tw, data, tid);         // starts with a barrier: every gather of the staged digits is done
         // ---- phase 2: this member's partials of its two output limb polynomials
 #pragma unroll
         for (int l = 0; l < LPM; l++) {
@@ -1805,9 +1815,10 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             for (int cin = 0; cin < NX; cin++) mac_regs(acc[0], x[cin], g[cin]);
             __builtin_amdgcn_sched_barrier(0);
             if (l + 1 < LPM) fetch(l + 1);     // arrives during the inverse transform
-            // at most two MAC terms: no initial reduction; buffer l: the previous transform in it was a forward one (fenced inside) or none
-            ntt_inv<1, false, false>(acc, tw, data + l * LDS_DATA, tid);
-            double* bgp = bigg + (long)((co * SK + j) * SX + r) * N;
+            // at most three MAC terms: no initial reduction; buffer l % 2: alternating, and the previous transform in buffers 0 and 1
+            // was a forward one (fenced inside) or none
+            ntt_inv<1, false, false>(acc, tw, data + (l & 1) * LDS_DATA, tid);
+            double* bgp = bigg + (long)((co * SK + j) * RS + r) * N;
 #pragma unroll
             for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
         }
@@ -1826,19 +1837,19 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
         // 2N items over MEMBERS * T threads: one or two per thread — both items' loads are issued before either is used (the
         // phase is one L2 round trip long, not two)
         constexpr int NIT = (2 * N + MEMBERS * T - 1) / (MEMBERS * T);
-        static_assert(NIT == 2, "two items per thread at most");
+        static_assert(NIT <= 4, "a few items per thread at most");
         double v_[NIT][SK], cqv[NIT], cbv[NIT];
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
             const int item = m * T + tid + u * MEMBERS * T;
             const bool on = item < 2 * N;
             const int nco = on ? item / N : 0, i = on ? item % N : 0;
-            const double* bgp = bigg + (long)nco * SK * SX * N + i;
+            const double* bgp = bigg + (long)nco * SK * RS * N + i;
 #pragma unroll
             for (int q = 0; q < SK; q++) {
-                v_[u][q] = ld_l2(bgp + (long)(q * SX) * N);
+                v_[u][q] = ld_l2(bgp + (long)(q * RS) * N);
 #pragma unroll
-                for (int w = 1; w < SX; w++) v_[u][q] += ld_l2(bgp + (long)(q * SX + w) * N);   // exact: integers below 2^50
+                for (int w = 1; w < RS; w++) v_[u][q] += ld_l2(bgp + (long)(q * RS + w) * N);   // exact: integers below 2^50
             }
             cqv[u] = 0.0;                      // TRACE: Y of the step's input at this coefficient (the `+ x` of the trace step)
             cbv[u] = 0.0;                      // TRACE, body column: Y of the input's body where phi_g takes this coefficient from

@@ -117,14 +117,21 @@ void run_chain(fheram_ctx* c, int n, GlweRef src, GlweRef dst, GlweRef tmp, int 
         cur = out;
     }
 }
-// Dependent chains on 9..16 ciphertexts (MAX_ADDR = 2^13, 2^14: the alone packer levels, the products of coordinate 0,
+// Dependent chains on 9..64 ciphertexts (MAX_ADDR = 2^13 .. 2^16: the alone packer levels, the products of coordinate 0,
 // write_mid_step's traces): ONE launch with in-kernel hand-offs (k_chain_mid), followed by the fused chain launch that redoes
-// the ciphertexts whose group gave up (normally none).
-bool use_mid(const fheram_ctx* c, int n, int gx, int gy) {
+// the ciphertexts whose group gave up (normally none).  Returns the split (0: not applicable; 1: <3,2>, 2: <1,1>, 3: <1,2>).
+int use_mid(const fheram_ctx* c, int n, int gx, int gy, int sk, bool ep = false) {
     const long batch = (long)gx * gy;
-    return c->mid && c->limb_split && n >= 2 && n <= CHAIN_MAX && batch > TAIL_GROUPS && batch <= MID_GROUPS_MAX &&
-           c->cus >= TAIL_GROUPS * 32 &&     // the whole chip (8 XCDs x 32 CUs)
-           !(c->use_graph && !c->profile);   // a captured launch would replay its generation number
+    if (!(c->mid && c->limb_split && n >= 2 && n <= CHAIN_MAX && batch > TAIL_GROUPS &&
+          c->cus >= TAIL_GROUPS * 32 &&      // the whole chip (8 XCDs x 32 CUs)
+          !(c->use_graph && !c->profile)))   // a captured launch would replay its generation number
+        return 0;
+    if (batch <= 16) return 1;
+    if (ep || c->mid < 2) return 0;          // the coarser splits: trace chains only
+    const int m1 = 2 * sk, m2 = sk;          // members of <1,1>, <1,2>
+    if (batch <= 8 * (32 / m1)) return 2;
+    if (batch <= 8 * (32 / m2)) return 3;
+    return 0;
 }
 template <bool EP>
 void fill_mid(fheram_ctx* c, MidArgs& ma, GlweRef src, GlweRef dst, int n, int gx, int gy) {
@@ -136,7 +143,12 @@ void fill_mid(fheram_ctx* c, MidArgs& ma, GlweRef src, GlweRef dst, int n, int g
     ma.give_up_at = c->mid_test ? n - 2 : -1;
 }
 // b: the buffers of the fallback chain (step i writes b[i & 1]; b[0] != src); the result lands in b[(n - 1) & 1], which may be src
-void launch_mid_trace(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy, int rot_mul, int rot_base) {
+template <int SK, int RS, int LPM>
+void launch_k_mid_trace(fheram_ctx* c, const MidArgs& ma) {
+    constexpr int members = RS * 2 * SK / LPM;
+    hipLaunchKernelGGL((k_chain_mid<false, SK, RS, LPM>), dim3(8 * (32 / members) * members), dim3(T), LDS_BYTES, c->cur, ma);
+}
+void launch_mid_trace(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy, int rot_mul, int rot_base, int split) {
     ProfScope ps(c, "keyswitch", (uint64_t)gx * gy, n);
     ProfScope pm(c, "keyswitch_mid_launch", (uint64_t)gx * gy * n, 1);
     MidArgs ma;
@@ -148,10 +160,10 @@ void launch_mid_trace(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int sta
     ca.done = ma.sync; ca.done_seq = ma.seq;
     for (int i = 0; i < n; i++) { ma.opnd[i] = ca.key[i] = trace_key(c, start + i); ma.ginv[i] = ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
     if (c->s_evk == 5) {
-        hipLaunchKernelGGL((k_chain_mid<false, 5>), dim3(8 * 2 * 15), dim3(T), LDS_BYTES, c->cur, ma);
+        if (split == 1) launch_k_mid_trace<5, 3, 2>(c, ma); else if (split == 2) launch_k_mid_trace<5, 1, 1>(c, ma); else launch_k_mid_trace<5, 1, 2>(c, ma);
         hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     } else {
-        hipLaunchKernelGGL((k_chain_mid<false, 4>), dim3(8 * 2 * 12), dim3(T), LDS_BYTES, c->cur, ma);
+        if (split == 1) launch_k_mid_trace<4, 3, 2>(c, ma); else if (split == 2) launch_k_mid_trace<4, 1, 1>(c, ma); else launch_k_mid_trace<4, 1, 2>(c, ma);
         hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }
 }
@@ -164,7 +176,7 @@ void launch_mid_ep(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const doub
     ca.src = src; ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.tw = c->d_tw; ca.n = d;
     ca.done = ma.sync; ca.done_seq = ma.seq;
     for (int i = 0; i < d; i++) { ma.opnd[i] = ca.ggsw[i] = prep + (size_t)i * fheram_ctx::GGSW; ma.ginv[i] = 1; }
-    hipLaunchKernelGGL((k_chain_mid<true, 4>), dim3(8 * 2 * 12), dim3(T), LDS_BYTES, c->cur, ma);
+    hipLaunchKernelGGL((k_chain_mid<true, 4, 3, 2>), dim3(8 * 2 * 12), dim3(T), LDS_BYTES, c->cur, ma);
     hipLaunchKernelGGL((k_ext_product_chain<3, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
 }
 // A dependent chain of n fused steps on the same ciphertexts runs as ONE launch when the batch is large enough
@@ -191,7 +203,7 @@ void launch_ep_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const do
 // CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): d external products.
 void ep_chain(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, const double* prep, int d, int gx, int gy) {
     if (gx <= 0 || gy <= 0) return;
-    if (use_mid(c, d, gx, gy)) {
+    if (use_mid(c, d, gx, gy, 4, true)) {
         GlweRef b[2];   // in place too (read_prepare_write): only the last step writes the destination
         if (chain_bufs(d, src, dst, tmp, b)) { launch_mid_ep(c, src, b, prep, d, gx, gy); return; }
     }
@@ -269,9 +281,9 @@ void trace_steps(fheram_ctx* c, GlweRef src, GlweRef dst, GlweRef tmp, int start
         GlweRef b[2];
         if (chain_bufs(n, src, dst, tmp, b) && !same(b[1], src)) { launch_trace_tail(c, src, b, start, n, gx, gy); return; }
     }
-    if (use_mid(c, n, gx, gy)) {
+    if (const int split = use_mid(c, n, gx, gy, c->s_evk)) {
         GlweRef b[2];
-        if (chain_bufs(n, src, dst, tmp, b)) { launch_mid_trace(c, src, b, start, n, gx, gy, rot_mul, rot_base); return; }
+        if (chain_bufs(n, src, dst, tmp, b)) { launch_mid_trace(c, src, b, start, n, gx, gy, rot_mul, rot_base, split); return; }
     }
     if (use_chain(c, n, gx, gy, c->s_evk) && !use_fine_split(c, gx, gy, 2 * c->s_evk * 3)) {
         GlweRef b[2];
@@ -316,11 +328,11 @@ int32_t* pack_levels(fheram_ctx* c, int32_t* src, int32_t* A, int32_t* B, long s
         launch_trace_tail(c, ref(cur, sy, sx), b, 0, n_alone, (int)count, gy);
         cur = ((n_alone - 1) & 1) ? b1 : b0;
     } else
-    if (count > 0 && use_mid(c, n_alone, (int)count, gy)) {
+    if (count > 0 && use_mid(c, n_alone, (int)count, gy, c->s_evk)) {
         int32_t* b0 = other(cur);
         int32_t* b1 = other(b0);
         const GlweRef b[2] = {ref(b0, sy, sx), ref(b1, sy, sx)};
-        launch_mid_trace(c, ref(cur, sy, sx), b, 0, n_alone, (int)count, gy, 0, 0);
+        launch_mid_trace(c, ref(cur, sy, sx), b, 0, n_alone, (int)count, gy, 0, 0, use_mid(c, n_alone, (int)count, gy, c->s_evk));
         cur = ((n_alone - 1) & 1) ? b1 : b0;
     } else
     if (count > 0 && use_chain(c, n_alone, (int)count, gy, c->s_evk) && !use_fine_split(c, (int)count, gy, 2 * c->s_evk * 3)) {
