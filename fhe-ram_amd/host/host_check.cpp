@@ -56,12 +56,12 @@ int main() {
         std::printf("address derived from an encrypted integer reads the same word: ok\n");
         // one handle over "two GPUs" (the same device twice: rehearsal): a group must refuse an operation before its keys
         // and RAM are loaded exactly as the single context does
-        fheram::GroupRam grp(fheram::Parameters(4, {3, 3, 3, 3}, 1 << 12), {0, 0});
+        fheram::GroupRam grp(fheram::Parameters(4, {3, 3, 3, 3}, 1 << 13), {0, 0});   // two rows per sub-RAM: one per shard
         if (grp.size() != 2) return 8;
         try { fheram::Address a2; grp.read(a2, fheram::EvaluationKeysPrepared()); return 9; }
         catch (const fheram::Error& e) { std::printf("group refused as the reference would: %s\n", e.what()); }
     } catch (const fheram::Error& e) {
-        if (e.code != FHERAM_ERR_DEVICE) return 4;
+        if (e.code != FHERAM_ERR_DEVICE) { std::printf("unexpected error %d: %s\n", e.code, e.what()); return 4; }
         std::printf("no GPU: %s\n", e.what());
     }
     return 0;
