@@ -19,6 +19,9 @@ python tools/trace_summary.py $O/stats 40 > $O/kernel_trace_by_grid.txt
 (cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python3 $R/bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-boundary --no-kernel-timing > $O/tl.json 2> $O/tl.err)
 python tools/trace_timeline.py $O/tl 0 100000 | tail -420 | head -260 > $O/timeline.txt   # steps of the timed region, no per-launch events
 rm -rf $O/tl
+(cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $O/tl14 -- python3 $R/bench.py --log-max-addr 14 --steps 2 --warmup 8 --no-cpu-baseline --no-boundary --no-kernel-timing > $O/tl14.json 2> $O/tl14.err)
+python tools/trace_timeline.py $O/tl14 0 100000 | tail -110 > $O/timeline_2_14.txt   # the source default size: the mid-batch chains
+rm -rf $O/tl14
 cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv
 python tools/pmc_hbm.py $O/cfetch $O/cwrite $O/fetch $O/write > $O/pmc_hbm_traffic.json
 python tools/pmc_sq_summary.py pmc_sq=$O/sq pmc_lds=$O/lds > $O/pmc_sq_summary.txt
@@ -31,7 +34,7 @@ python bench.py --workload ep > $O/bench_ep.json 2> $O/bench_ep.err
 python bench.py --params readme > $O/bench_readme.json 2> $O/bench_readme.err
 python tools/chain_bench.py 256 600 > $O/chain_bench.txt 2>&1
 ( echo "# python bench.py --log-max-addr K --steps 20 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary   (one MI355X, WORDSIZE 4)"; echo "log2(MAX_ADDR)  read_ms  rpw_ms  write_ms  ms_per_step  RAM ops/s  single-launch trace chains / fallbacks   mid-batch chains / fallbacks";
-  for K in 12 14 16 18 20 21 22 24; do ST=20; [ $K -ge 22 ] && ST=4; python bench.py --log-max-addr $K --steps $ST --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%6d %10.3f %9.3f %9.3f %10.3f %10.1f   %d/%d   %d/%d' % ($K, d['read_ms'], d['read_prepare_write_ms'], d['write_ms'], d['ms_per_step'], d['value'], d['trace_tail']['launches'], d['trace_tail']['fallbacks'], d['mid_chain']['launches'], d['mid_chain']['fallbacks']))"; done ) > $O/size_sweep.txt
+  for K in 12 13 14 15 16 18 20 21 22 24; do ST=20; [ $K -ge 22 ] && ST=4; python bench.py --log-max-addr $K --steps $ST --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%6d %10.3f %9.3f %9.3f %10.3f %10.1f   %d/%d   %d/%d' % ($K, d['read_ms'], d['read_prepare_write_ms'], d['write_ms'], d['ms_per_step'], d['value'], d['trace_tail']['launches'], d['trace_tail']['fallbacks'], d['mid_chain']['launches'], d['mid_chain']['fallbacks']))"; done ) > $O/size_sweep.txt
 ./tools/ntt_bench > $O/ntt_bench.txt 2>&1
 ./tools/xcd_handoff > $O/xcd_handoff.txt 2>&1
 ./tools/xcd_barrier > $O/xcd_barrier.txt 2>&1
