@@ -6,7 +6,7 @@ after a hand-off would show here), one ciphertext per round is compared with the
 another context busy with chip-filling launches so that the groups assemble under changing CU availability.  At the
 end the launch / fallback counters are printed (fallbacks are legal: their results are checked like any other).
 
-    python tests/soak_tail_gpu.py [seconds] [seed]        (needs an MI355X)
+    python tests/soak_tail_gpu.py [seconds] [seed] [min_batch max_batch]       (needs an MI355X; 9 64: the same for k_chain_mid)
 """
 import os
 import sys
@@ -22,7 +22,8 @@ import pyoracle as po  # noqa: E402
 from _pkg import load_package  # noqa: E402
 
 
-def main(seconds=120, seed=None, disturb=True):
+def main(seconds=120, seed=None, disturb=True, batches=(1, 8)):
+    """batches: inclusive range of the batch sizes drawn: (1, 8) = k_trace_tail's territory, (9, 64) = k_chain_mid's"""
     pkg = load_package()
     o = po.Oracle(po.OParams(max_addr=1 << 14))
     sk = o.secret_gen(1)
@@ -57,7 +58,7 @@ def main(seconds=120, seed=None, disturb=True):
     rounds = checks = 0
     try:
         while time.time() < t_end and not errs:
-            batch = int(rng.integers(1, 9))
+            batch = int(rng.integers(batches[0], batches[1] + 1))
             s = int(rng.integers(0, 11))
             e = int(rng.integers(s + 2, 13))
             a = rng.integers(-(1 << 16), 1 << 16, size=(batch, glen), dtype=np.int64)
@@ -78,10 +79,11 @@ def main(seconds=120, seed=None, disturb=True):
         if th:
             th.join()
     assert not errs, errs
-    st = ram.tail_stats()
+    st = ram.tail_stats() if batches[1] <= 8 else ram.mid_stats()
     print(f"tail soak ok: {rounds} rounds ({3 * rounds} launches), {checks} oracle checks in {seconds} s; {st}", flush=True)
     return rounds, st
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else None)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else None,
+         batches=(int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1, 8))

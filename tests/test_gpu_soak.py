@@ -31,6 +31,15 @@ def test_soak_single_launch_trace_chain(po):
     assert rounds >= 5 and st["launches"] >= 3 * rounds and st["fallbacks"] <= st["launches"]
 
 
+def test_soak_mid_batch_chains(po):
+    """The same for k_chain_mid: random batches of 9..64 ciphertexts (12 / 8 / 4 workgroups per ciphertext on one XCD,
+    in-kernel hand-offs, giving up per ciphertext) while a second context competes for the CUs: reproducible, exact, and
+    whatever gave up was redone."""
+    import soak_tail_gpu
+    rounds, st = soak_tail_gpu.main(seconds=15, seed=20261006, batches=(9, 64))
+    assert rounds >= 5 and st["launches"] >= 3 * rounds
+
+
 @pytest.mark.parametrize("params", ["source", "readme"])
 def test_noise_growth_over_consecutive_write_cycles(po, params):
     """BASELINE.json configs[3] 'noise growth checked': a bounded run of tests/noise_growth_gpu.py (the long one is
