@@ -139,7 +139,9 @@ struct fheram_ctx {
     int mid = 2;
     int mid_test = 0;
     unsigned mid_seq = 0;
-    uint64_t mid_launches = 0;
+    uint64_t mid_launches = 0, mid_launch_mark = 0;
+    unsigned mid_fb_mark = 0;
+    unsigned* h_mid_fb = nullptr;      // pinned, device-visible: ciphertexts redone, [0] main stream, [16] side stream
     unsigned* d_mid_sync[2] = {nullptr, nullptr};   // [64 groups][32] + [_, ciphertexts redone]: main / side stream
     double* d_mid_y[2] = {nullptr, nullptr};        // [2][64 groups][2][N] doubles: the chain's intermediates in the one-double form
     //  inv_id[ci]: d_prep_inv holds the prepared INVERSE digits of coordinate ci of the address with that id

@@ -212,6 +212,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     }
     CCHK(hipHostMalloc((void**)&c->h_tail_fb, 64, hipHostMallocDefault));
     *c->h_tail_fb = 0;
+    CCHK(hipHostMalloc((void**)&c->h_mid_fb, 128, hipHostMallocDefault));
+    memset(c->h_mid_fb, 0, 128);
     CCHK(hipHostMalloc((void**)&c->h_res, (size_t)c->ws * G * sizeof(int64_t), hipHostMallocMapped));
     CCHK(hipHostGetDevicePointer((void**)&c->d_h_res, c->h_res, 0));
     CCHK(hipHostMalloc((void**)&c->h_w, (size_t)c->ws * G * sizeof(int32_t), hipHostMallocDefault));
@@ -241,6 +243,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv, c->d_mid_sync[0], c->d_mid_sync[1], c->d_mid_y[0], c->d_mid_y[1]};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
+    if (c->h_mid_fb) hipHostFree(c->h_mid_fb);
     if (c->h_res) hipHostFree(c->h_res);
     if (c->h_w) hipHostFree(c->h_w);
     if (c->ev_w) hipEventDestroy(c->ev_w);

@@ -420,13 +420,17 @@ struct EpChainArgs {
     int n;
     unsigned* done = nullptr;        // fallback launch behind k_chain_mid: a ciphertext is redone unless done[ct * 32 + 3] == done_seq
     unsigned done_seq = 0;
+    unsigned* host_count = nullptr;  // pinned host word that mirrors the number of ciphertexts redone (read by the host without a sync)
 };
 template <int SA, int SG>
 __global__ __launch_bounds__(T, T / 256) void k_ext_product_chain(EpChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.done) {
         if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
-        if (threadIdx.x == 0) atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u);   // ciphertexts redone (fheram_mid_stats)
+        if (threadIdx.x == 0) {
+            const unsigned taken = atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u) + 1u;   // ciphertexts redone (fheram_mid_stats)
+            if (ca.host_count) __hip_atomic_store(ca.host_count, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     GlweRef in = ca.src;
 #pragma unroll 1
@@ -1089,7 +1093,10 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
     }
     if (ca.done) {
         if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
-        if (threadIdx.x == 0) atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u);   // ciphertexts redone (fheram_mid_stats)
+        if (threadIdx.x == 0) {
+            const unsigned taken = atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u) + 1u;   // ciphertexts redone (fheram_mid_stats)
+            if (ca.host_count) __hip_atomic_store(ca.host_count, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     KsArgs ka = ca.base;
 #pragma unroll 1

@@ -139,6 +139,12 @@ void fill_mid(fheram_ctx* c, MidArgs& ma, GlweRef src, GlweRef dst, int n, int g
     ma.src = src; ma.dst = dst; ma.tw = c->d_tw; ma.big = big_of(c); ma.sync = c->d_mid_sync[side]; ma.y = c->d_mid_y[side];
     if (++c->mid_seq == 0) ++c->mid_seq;
     c->mid_launches++;
+    if (!c->mid_test && c->mid_launches - c->mid_launch_mark >= 64) {   // as the tail: a context that keeps losing its CUs to others stops asking
+        const unsigned fb = ((volatile unsigned*)c->h_mid_fb)[0] + ((volatile unsigned*)c->h_mid_fb)[16];
+        if (fb - c->mid_fb_mark > 16) c->mid = 0;      // takes effect from the next chain on
+        c->mid_fb_mark = fb;
+        c->mid_launch_mark = c->mid_launches;
+    }
     ma.seq = c->mid_seq; ma.n = n; ma.n_ct = gx * gy; ma.gx = gx; ma.rot_mul = 0; ma.rot_base = 0;
     ma.give_up_at = c->mid_test ? n - 2 : -1;
 }
@@ -157,7 +163,7 @@ void launch_mid_trace(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int sta
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
-    ca.done = ma.sync; ca.done_seq = ma.seq;
+    ca.done = ma.sync; ca.done_seq = ma.seq; ca.host_count = c->h_mid_fb + (c->cur == c->stream2 ? 16 : 0);
     for (int i = 0; i < n; i++) { ma.opnd[i] = ca.key[i] = trace_key(c, start + i); ma.ginv[i] = ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
     if (c->s_evk == 5) {
         if (split == 1) launch_k_mid_trace<5, 3, 2>(c, ma); else if (split == 2) launch_k_mid_trace<5, 1, 1>(c, ma); else launch_k_mid_trace<5, 1, 2>(c, ma);
@@ -174,7 +180,7 @@ void launch_mid_ep(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const doub
     fill_mid<true>(c, ma, src, b[(d - 1) & 1], d, gx, gy);
     EpChainArgs ca;
     ca.src = src; ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.tw = c->d_tw; ca.n = d;
-    ca.done = ma.sync; ca.done_seq = ma.seq;
+    ca.done = ma.sync; ca.done_seq = ma.seq; ca.host_count = c->h_mid_fb + (c->cur == c->stream2 ? 16 : 0);
     for (int i = 0; i < d; i++) { ma.opnd[i] = ca.ggsw[i] = prep + (size_t)i * fheram_ctx::GGSW; ma.ginv[i] = 1; }
     hipLaunchKernelGGL((k_chain_mid<true, 4, 3, 2>), dim3(8 * 2 * 12), dim3(T), LDS_BYTES, c->cur, ma);
     hipLaunchKernelGGL((k_ext_product_chain<3, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
