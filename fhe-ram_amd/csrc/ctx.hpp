@@ -175,7 +175,7 @@ struct fheram_ctx {
     hipEvent_t ev_w = nullptr;
     bool w_busy = false;
     // profiling
-    bool profile = false;
+    int profile = 0;               // 1: every launch class bracketed by HIP events; 2: only the chain launches themselves (two events per launch: leaves back-to-back submission intact)
     std::map<std::string, ProfCls> prof;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -231,6 +231,7 @@ struct ProfScope {
     // so that ms / launches stays the time of ONE round over `blocks / launches` ciphertexts
     ProfScope(fheram_ctx* c_, const char* name, uint64_t blocks, int steps = 1) : c(c_) {
         if (!c->profile) return;
+        if (c->profile == 2 && !strstr(name, "chain_launch")) return;
         cls = &c->prof[name];
         cls->launches += steps; cls->blocks += blocks * steps;
         a = get_event(c);

@@ -660,7 +660,7 @@ int fheram_timer_end(fheram_ctx* c, float* ms) {
 }
 int fheram_profile_enable(fheram_ctx* c, int on) {
     if (!c) return FHERAM_ERR_INVALID_ARG;
-    c->profile = on != 0;
+    c->profile = on == 2 ? 2 : (on != 0);   // 2: the chain launches only
     return FHERAM_OK;
 }
 int fheram_profile_reset(fheram_ctx* c) {

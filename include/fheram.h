@@ -276,7 +276,9 @@ int fheram_timer_begin(fheram_ctx* ctx);
 int fheram_timer_end(fheram_ctx* ctx, float* elapsed_ms);
 /* Per-kernel-class timing: when enabled, every launch of the hot kernels is bracketed by HIP
  * events on the launch stream; totals are read back per class name
- * ("ext_product", "keyswitch", "prepare", "elementwise"). */
+ * ("ext_product", "keyswitch", "prepare", "elementwise").  on = 2: only the chain launches themselves
+ * ("keyswitch_chain_launch": two events per launch of the dominant kernel, nothing else — back-to-back submission of
+ * the other launches stays as in an unprofiled run). */
 int fheram_profile_enable(fheram_ctx* ctx, int on);
 int fheram_profile_get(fheram_ctx* ctx, const char* kernel_class, uint64_t* launches, uint64_t* blocks, double* total_ms);
 int fheram_profile_reset(fheram_ctx* ctx);
