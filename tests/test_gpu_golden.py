@@ -66,6 +66,24 @@ def test_hip_flow_matches_committed_digests(po, key):
     assert out == d["outputs"]
 
 
+@pytest.mark.parametrize("env", [{"FHERAM_LIMB_SPLIT": "0", "FHERAM_NCO": "1"}, {"FHERAM_LIMB_SPLIT": "0", "FHERAM_NCO": "2", "FHERAM_CHAIN": "0"},
+                                 {"FHERAM_FINE_SPLIT": "0"}, {"FHERAM_MEMO": "0"}, {"FHERAM_GRAPH": "1"}, {"FHERAM_TAIL": "2"},
+                                 {"FHERAM_CHAIN_Y": "0"}, {"FHERAM_PRE_INV": "0"}],
+                         ids=["column-split", "fused-unchained", "limb-parallel", "write-recomputes", "hipgraph-replay", "tail-gives-up",
+                              "limb-handover", "write-inverts"])
+def test_forced_decompositions_reproduce_the_2_18_digests(env):
+    """The launch heuristics are tuned on one chip shape and one RAM size; every alternative decomposition is forced at 2^14
+    in test_gpu_parity.py — and here at the FULL size of BASELINE.json configs[2..3] (256 ciphertexts per round: the fused chain
+    kernels, the column split, the memo between read_prepare_write and write, graph replay, the tail's fallback): the
+    committed 2^18 digests must come out whatever path computes them (child process: the switches are read at context creation)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                        os.path.join(root, "tests", "test_gpu_golden.py") + "::test_hip_flow_matches_committed_digests[262144]"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("n_shards,max_addr,device_buffers",
                          [(8, 1 << 18, False), (8, 1 << 18, True), (8, 1 << 21, True), (2, 1 << 21, False)])
 def test_sharded_flow_matches_committed_digests(po, n_shards, max_addr, device_buffers):
