@@ -56,10 +56,22 @@ __device__ unsigned long long g_stamps[192];
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
+// k_chain_mid: every member of ciphertext 0, step FK_STAMP_STEP: g_stamps[stamp * 24 + member]
+#define MSTAMP(i)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (threadIdx.x == 0 && s == FK_STAMP_STEP && ctg == 0) {                                  \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            g_stamps[(i) * 24 + m] = t_;                                                           \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMPZ(i) do { } while (0)
 #define TSTAMP(i) do { } while (0)
+#define MSTAMP(i) do { } while (0)
 #endif
 
 struct GlweRef {   // p + y*sy + x*sx  (int32 elements)
@@ -1744,6 +1756,7 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
     int32_t* op = ma.dst.p + cty * ma.dst.sy + ctx_ * ma.dst.sx;
     const int rho = -(ma.rot_base + (int)ctx_ * ma.rot_mul);         // first TRACE step only
     unsigned epoch = 0;
+    OpRegs g[NX];
 #pragma unroll 1
     for (int s = 0; s < ma.n; s++) {
         const double* yin = ma.y + ((long)((s + 1) & 1) * MID_GROUPS_MAX + ctg) * (2 * N);   // [col][N], written by step s - 1
@@ -1754,9 +1767,11 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
         __builtin_assume(tid >= 0 && tid < T);
         const int ginv = EP ? 1 : ma.ginv[s];
         const int sidx0 = (tid * ginv) & (2 * N - 1), sstep = (T * ginv) & (2 * N - 1);
-        // the one-double form of column `col` at natural coefficient i: A (EP) or Y = ceil(A/2) (TRACE)
-        auto one_double = [&](int col, int i) -> double {
-            if (!first) return ld_l2(yin + (long)col * N + i);       // written by the other members of the group: past the L1
+        // the one-double form of column `col` at natural coefficient i: A (EP) or Y = ceil(A/2) (TRACE).  Inner steps read it
+        // from the scratch the other members of the group wrote (past the L1); the first step makes it from the int32 source.
+        // The two cases are kept apart at every use (`if (first)` around whole load loops, never inside one): a branch per
+        // load put every L2 round trip behind the previous one (8 in a row: 3.2 us of a 15 us step, tools/stamp_mid.py)
+        auto raw_double = [&](int col, int i) -> double {
             int src = i; bool neg = false;
             if constexpr (!EP) rot_src(i, rho, src, neg);
             double a = __builtin_fma(__builtin_fma((double)ap[glwe_off(0, col) + src], TWO_B, (double)ap[glwe_off(1, col) + src]), TWO_B,
@@ -1772,30 +1787,54 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             if (r < 1) d = c;
             return d;
         };
-        OpRegs g[NX];
-        auto fetch = [&](int l) {
+        auto fetch = [&](int step, int l) {
             const int pi = h * LPM + l, co = pi / SK, j = SK - 1 - pi % SK;
 #pragma unroll
             for (int cin = 0; cin < NX; cin++)   // operand row: EP: digit r of column cin;  TRACE: digit r (RS == 1: digit cin)
-                load_ops(g[cin], ma.opnd[s] + (long)(((EP ? (2 * r + cin) : (RS == 1 ? cin : r)) * SK + j) * 2 + co) * N, tid);
+                load_ops(g[cin], ma.opnd[step] + (long)(((EP ? (2 * r + cin) : (RS == 1 ? cin : r)) * SK + j) * 2 + co) * N, tid);
         };
-        fetch(0);                              // arrives during phase 1
+        MSTAMP(0);
+        // (the operands of this step's first polynomial were requested during the previous step — or, for the first step, are
+        // requested below, BEHIND the input loads: loads return in order, and the inputs are what phase 1 waits for)
         // ---- phase 1: digit r of the input (TRACE: of the mask column through phi_g), forward transform(s)
         double x[NX][E];
         if constexpr (EP) {
+            if (first) {                       // the limbs as they are stored (they need not be normalised: a rotation's negation leaves +2^16)
+                int xi[2][E];
 #pragma unroll
-            for (int col = 0; col < 2; col++) {
-                if (first) {                   // the limbs as they are stored (they need not be normalised: a rotation's negation leaves +2^16)
+                for (int col = 0; col < 2; col++)
 #pragma unroll
-                    for (int k = 0; k < E; k++) x[col][k] = (double)ap[glwe_off(r, col) + tid + T * k];
-                } else {
+                    for (int k = 0; k < E; k++) xi[col][k] = ap[glwe_off(r, col) + tid + T * k];
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(0, 0);
 #pragma unroll
-                    for (int k = 0; k < E; k++) x[col][k] = digit_r(one_double(col, tid + T * k));
-                }
+                for (int col = 0; col < 2; col++)
+#pragma unroll
+                    for (int k = 0; k < E; k++) x[col][k] = (double)xi[col][k];
+            } else {
+                double yv[2][E];
+#pragma unroll
+                for (int col = 0; col < 2; col++)
+#pragma unroll
+                    for (int k = 0; k < E; k++) yv[col][k] = ld_l2(yin + (long)col * N + tid + T * k);
+#pragma unroll
+                for (int col = 0; col < 2; col++)
+#pragma unroll
+                    for (int k = 0; k < E; k++) x[col][k] = digit_r(yv[col][k]);
             }
         } else {
+            double yv[E];
+            if (first) {
 #pragma unroll
-            for (int k = 0; k < E; k++) { const double c = one_double(1, tid + T * k); stage0[tid + T * k] = (RS == 1) ? c : digit_r(c); }
+                for (int k = 0; k < E; k++) yv[k] = raw_double(1, tid + T * k);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < E; k++) yv[k] = ld_l2(yin + (long)N + tid + T * k);
+            }
+#pragma unroll
+            for (int k = 0; k < E; k++) stage0[tid + T * k] = (RS == 1) ? yv[k] : digit_r(yv[k]);
             __syncthreads();
             int sidx = sidx0;
 #pragma unroll
@@ -1810,7 +1849,9 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
                 sidx = (sidx + sstep) & (2 * N - 1);
             }
         }
+        MSTAMP(1);
         fwd_all<NX>(x, tw, data, tid);         // starts with a barrier: every gather of the staged digits is done
+        MSTAMP(2);
         // ---- phase 2: this member's partials of its two output limb polynomials
 #pragma unroll
         for (int l = 0; l < LPM; l++) {
@@ -1821,7 +1862,8 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
 #pragma unroll
             for (int cin = 0; cin < NX; cin++) mac_regs(acc[0], x[cin], g[cin]);
             __builtin_amdgcn_sched_barrier(0);
-            if (l + 1 < LPM) fetch(l + 1);     // arrives during the inverse transform
+            if (l + 1 < LPM) fetch(s, l + 1);  // arrives during the inverse transform
+            else if (!last) fetch(s + 1, 0);   // the next step's first operands: they arrive during the hand-offs
             // at most three MAC terms: no initial reduction; buffer l % 2: alternating, and the previous transform in buffers 0 and 1
             // was a forward one (fenced inside) or none
             ntt_inv<1, false, false>(acc, tw, data + (l & 1) * LDS_DATA, tid);
@@ -1829,11 +1871,13 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
 #pragma unroll
             for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
         }
+        MSTAMP(3);
         if (ma.give_up_at == s && ctg == 0 && m == 1) {
             if (tid == 0) __hip_atomic_fetch_or(ctr, MID_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         if (!mid_barrier(ctr, (++epoch) * MEMBERS, flag, tid)) break;
+        MSTAMP(4);
         if (first) {                           // placement: all members of the group on one XCD (they all read the same mask: all stay or all leave)
             if (__builtin_popcount(__hip_atomic_load(ctr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 1) {
                 if (tid == 0) __hip_atomic_fetch_or(ctr, MID_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1860,9 +1904,27 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             }
             cqv[u] = 0.0;                      // TRACE: Y of the step's input at this coefficient (the `+ x` of the trace step)
             cbv[u] = 0.0;                      // TRACE, body column: Y of the input's body where phi_g takes this coefficient from
-            if constexpr (!EP) {
-                cqv[u] = one_double(nco, i);
-                if (nco == 0) cbv[u] = one_double(0, (i * ginv) & (N - 1));
+        }
+        if constexpr (!EP) {
+            if (first) {
+#pragma unroll
+                for (int u = 0; u < NIT; u++) {
+                    const int item = m * T + tid + u * MEMBERS * T;
+                    const bool on = item < 2 * N;
+                    const int nco = on ? item / N : 0, i = on ? item % N : 0;
+                    cqv[u] = raw_double(nco, i);
+                    if (nco == 0) cbv[u] = raw_double(0, (i * ginv) & (N - 1));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NIT; u++) {
+                    const int item = m * T + tid + u * MEMBERS * T;
+                    const bool on = item < 2 * N;
+                    const int nco = on ? item / N : 0, i = on ? item % N : 0;
+                    cqv[u] = ld_l2(yin + (long)nco * N + i);
+                    const double t = ld_l2(yin + ((i * ginv) & (N - 1)));   // column 0; unused (but harmless) for a mask-column item
+                    cbv[u] = (nco == 0) ? t : 0.0;
+                }
             }
         }
 #pragma unroll
@@ -1901,7 +1963,9 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
                 yout[(long)nco * N + i] = EP ? ad : __builtin_floor(__builtin_fma(ad, 0.5, 0.5));
             }
         }
+        MSTAMP(5);
         if (!last && !mid_barrier(ctr, (++epoch) * MEMBERS, flag, tid)) break;
+        MSTAMP(6);
     }
     // the last workgroup of the group to leave (every one passes here exactly once, given up or not) records whether the
     // group completed and rewinds the group's words for the next launch: nobody can still be waiting on them
