@@ -1310,9 +1310,13 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
         TSTAMP(4);
         if (!tail_barrier(ctr, abortp, ta.seq, (++epoch) * G, flag, s == 0, tid)) break;
         TSTAMP(5);
-        // ---- normalisation phase: one thread per (column, coefficient); same arithmetic as k_keyswitch_norm<KS_TRACE>
-        const int gid = m * T + tid;
-        if (gid < 2 * N) {
+        // ---- normalisation phase: one thread per (column, coefficient); same arithmetic as k_keyswitch_norm<KS_TRACE>.
+        // Every member takes an equal share of the 2N coefficients (CH consecutive ones: the phase is as long as its busiest
+        // member's L2 reads; with T per member a third of the members had none)
+        constexpr int CH = (2 * N + G - 1) / G;
+        static_assert(CH <= T, "one coefficient per thread");
+        const int gid = m * CH + tid;
+        if (tid < CH && gid < 2 * N) {
             const int nco = gid / N, i = gid % N;
             const double* bgp = bigg + (long)nco * SK * SX * N + i;
             double v_[SK];
@@ -1885,23 +1889,19 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             }
         }
         // ---- normalisation phase: one thread per (column, coefficient): same arithmetic as the emit step of the fused kernels.
-        // 2N items over MEMBERS * T threads: one or two per thread — both items' loads are issued before either is used (the
-        // phase is one L2 round trip long, not two)
-        constexpr int NIT = (2 * N + MEMBERS * T - 1) / (MEMBERS * T);
+        // 2N items over MEMBERS * T threads: a few per thread — all their loads are issued before any is used (the phase is one L2
+        // round trip long)
+        // member m owns the CH consecutive items from m * CH on (an equal share for every member — the phase is as long as its
+        // busiest member's L2 reads —, consecutive items on consecutive lanes); thread t takes items t, t + T, ... of the share
+        constexpr int CH = (2 * N + MEMBERS - 1) / MEMBERS;
+        constexpr int NIT = (CH + T - 1) / T;
         static_assert(NIT <= 4, "a few items per thread at most");
+        const int ibase = m * CH, icount = (2 * N - ibase) < CH ? (2 * N - ibase) : CH;
         double v_[NIT][SK], cqv[NIT], cbv[NIT];
+        // the step's input at these coefficients first (loads only, nothing used yet: the sums below wait for their own loads,
+        // and a load issued behind that wait would be a second round trip)
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
-            const int item = m * T + tid + u * MEMBERS * T;
-            const bool on = item < 2 * N;
-            const int nco = on ? item / N : 0, i = on ? item % N : 0;
-            const double* bgp = bigg + (long)nco * SK * RS * N + i;
-#pragma unroll
-            for (int q = 0; q < SK; q++) {
-                v_[u][q] = ld_l2(bgp + (long)(q * RS) * N);
-#pragma unroll
-                for (int w = 1; w < RS; w++) v_[u][q] += ld_l2(bgp + (long)(q * RS + w) * N);   // exact: integers below 2^50
-            }
             cqv[u] = 0.0;                      // TRACE: Y of the step's input at this coefficient (the `+ x` of the trace step)
             cbv[u] = 0.0;                      // TRACE, body column: Y of the input's body where phi_g takes this coefficient from
         }
@@ -1909,8 +1909,8 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             if (first) {
 #pragma unroll
                 for (int u = 0; u < NIT; u++) {
-                    const int item = m * T + tid + u * MEMBERS * T;
-                    const bool on = item < 2 * N;
+                    const int item = ibase + tid + u * T;
+                    const bool on = tid + u * T < icount;
                     const int nco = on ? item / N : 0, i = on ? item % N : 0;
                     cqv[u] = raw_double(nco, i);
                     if (nco == 0) cbv[u] = raw_double(0, (i * ginv) & (N - 1));
@@ -1918,8 +1918,8 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             } else {
 #pragma unroll
                 for (int u = 0; u < NIT; u++) {
-                    const int item = m * T + tid + u * MEMBERS * T;
-                    const bool on = item < 2 * N;
+                    const int item = ibase + tid + u * T;
+                    const bool on = tid + u * T < icount;
                     const int nco = on ? item / N : 0, i = on ? item % N : 0;
                     cqv[u] = ld_l2(yin + (long)nco * N + i);
                     const double t = ld_l2(yin + ((i * ginv) & (N - 1)));   // column 0; unused (but harmless) for a mask-column item
@@ -1929,8 +1929,21 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
         }
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
-            const int item = m * T + tid + u * MEMBERS * T;
-            if (item >= 2 * N) break;
+            const int item = ibase + tid + u * T;
+            const bool on = tid + u * T < icount;
+            const int nco = on ? item / N : 0, i = on ? item % N : 0;
+            const double* bgp = bigg + (long)nco * SK * RS * N + i;
+#pragma unroll
+            for (int q = 0; q < SK; q++) {
+                v_[u][q] = ld_l2(bgp + (long)(q * RS) * N);
+#pragma unroll
+                for (int w = 1; w < RS; w++) v_[u][q] += ld_l2(bgp + (long)(q * RS + w) * N);   // exact: integers below 2^50
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; u++) {
+            const int item = ibase + tid + u * T;
+            if (tid + u * T >= icount) break;
             const int nco = item / N, i = item % N;
             double cq = cqv[u], cb = cbv[u];
             const bool ngb = ((i * ginv) & (2 * N - 1)) >= N;   // phi_g: X^N = -1
