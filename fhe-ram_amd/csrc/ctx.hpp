@@ -143,6 +143,7 @@ struct fheram_ctx {
     unsigned mid_fb_mark = 0;
     unsigned* h_mid_fb = nullptr;      // pinned, device-visible: ciphertexts redone, [0] main stream, [16] side stream
     unsigned* d_mid_sync[2] = {nullptr, nullptr};   // [64 groups][32] + [_, ciphertexts redone]: main / side stream
+    double* d_mid_big[2] = {nullptr, nullptr};      // [step parity][ciphertext x RS <= 64] x BIG_STRIDE doubles: k_chain_mid's partial limb polynomials
     double* d_mid_y[2] = {nullptr, nullptr};        // [2][64 groups][2][N] doubles: the chain's intermediates in the one-double form
     //  inv_id[ci]: d_prep_inv holds the prepared INVERSE digits of coordinate ci of the address with that id
     //              (CoordinatePrepared::prepare_inv, ram.rs:260-271,278-289): read_prepare_write — which is told the

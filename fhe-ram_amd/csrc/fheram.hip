@@ -209,6 +209,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         CCHK(hipMalloc(&c->d_mid_sync[i], (size_t)(MID_GROUPS_MAX + 1) * 32 * sizeof(unsigned)));
         CCHK(hipMemset(c->d_mid_sync[i], 0, (size_t)(MID_GROUPS_MAX + 1) * 32 * sizeof(unsigned)));
         CCHK(hipMalloc(&c->d_mid_y[i], (size_t)2 * MID_GROUPS_MAX * 2 * N * sizeof(double)));
+        CCHK(hipMalloc(&c->d_mid_big[i], (size_t)2 * MID_GROUPS_MAX * BIG_STRIDE * sizeof(double)));
     }
     CCHK(hipHostMalloc((void**)&c->h_tail_fb, 64, hipHostMallocDefault));
     *c->h_tail_fb = 0;
@@ -240,7 +241,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     for (int b = 0; b < 2; b++) { if (c->ev_pin[b]) hipEventDestroy(c->ev_pin[b]); if (c->h_pin[b]) hipHostFree(c->h_pin[b]); }
-    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv, c->d_mid_sync[0], c->d_mid_sync[1], c->d_mid_y[0], c->d_mid_y[1]};
+    void* bufs[] = {c->d_tw, c->d_atk, c->d_atk_inv, c->d_tsk, c->d_data, c->d_scrA, c->d_scrB, c->d_big, c->d_big2, c->d_scrC, c->d_scrD, c->d_ggsw_tmp2, c->d_tmp2, c->d_part, c->d_gat[0], c->d_gat[1], c->d_gat[2], c->d_tree, c->d_res, c->d_tmp, c->d_w, c->d_trtop, c->d_prep, c->d_ggsw_tmp, c->d_tail_sync, c->d_prep_inv, c->d_ggsw_inv, c->d_mid_sync[0], c->d_mid_sync[1], c->d_mid_y[0], c->d_mid_y[1], c->d_mid_big[0], c->d_mid_big[1]};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
     if (c->h_mid_fb) hipHostFree(c->h_mid_fb);

@@ -1728,6 +1728,32 @@ __device__ __forceinline__ bool mid_barrier(unsigned* ctr, unsigned want, int* f
     __syncthreads();
     return *flag != 0;
 }
+// The same in two halves: a member announces its arrival (its stores so far drained) and goes on with work nobody waits for;
+// the wait comes when it needs what the others announced.
+__device__ __forceinline__ void mid_arrive(unsigned* ctr, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool mid_wait(unsigned* ctr, unsigned want, int* flag, int tid) {
+    if (tid == 0) {
+        unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = -1;
+        for (int spin = 0; spin < TAIL_SPIN_MAX && ok < 0; spin++) {
+            if (v & MID_POISON) ok = 0;
+            else if (v >= want) ok = 1;
+            else v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        while (ok < 0) {
+            if (v & MID_POISON) ok = 0;
+            else if (v >= want) ok = 1;
+            else if (__hip_atomic_compare_exchange_strong(ctr, &v, v | MID_POISON, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
 template <bool EP, int SK, int RS, int LPM>
 __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1750,7 +1776,7 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
     int* flag = reinterpret_cast<int*>(lds + LDS_TW + BMAX * LDS_DATA - 2);   // the padding at the very end of the LDS allocation
     unsigned* ctr = ma.sync + ctg * 32;
     const long cty = (long)(ctg / ma.gx), ctx_ = (long)(ctg % ma.gx);
-    double* bigg = ma.big + (long)ctg * BIG_STRIDE * RS;
+    double* const big0 = ma.big + (long)ctg * BIG_STRIDE * RS;   // + step parity * n_ct * BIG_STRIDE * RS (see the normalisation phase)
     if (tid == 0) {
         __hip_atomic_fetch_or(ctr + 2, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // performed before this workgroup's first arrival is counted
@@ -1766,6 +1792,7 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
         const double* yin = ma.y + ((long)((s + 1) & 1) * MID_GROUPS_MAX + ctg) * (2 * N);   // [col][N], written by step s - 1
         double* yout = ma.y + ((long)(s & 1) * MID_GROUPS_MAX + ctg) * (2 * N);
         const bool first = (s == 0), last = (s + 1 == ma.n);
+        double* const bigg = big0 + (long)(s & 1) * ma.n_ct * BIG_STRIDE * RS;
         tid = tid0;
         asm volatile("" : "+v"(tid));   // per-step copy the optimiser cannot see through (see k_ext_product_chain)
         __builtin_assume(tid >= 0 && tid < T);
@@ -1889,95 +1916,104 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             }
         }
         // ---- normalisation phase: one thread per (column, coefficient): same arithmetic as the emit step of the fused kernels.
-        // 2N items over MEMBERS * T threads: a few per thread — all their loads are issued before any is used (the phase is one L2
-        // round trip long)
-        // member m owns the CH consecutive items from m * CH on (an equal share for every member — the phase is as long as its
-        // busiest member's L2 reads —, consecutive items on consecutive lanes); thread t takes items t, t + T, ... of the share
-        constexpr int CH = (2 * N + MEMBERS - 1) / MEMBERS;
+        // Member m owns CH consecutive coefficients of each column (an equal share for every member: the phase is as long as its
+        // busiest member's L2 reads; consecutive coefficients on consecutive lanes); all loads of a share are issued before any
+        // is used (one L2 round trip).  A trace step's NEXT fine phase needs the mask column only: the members announce
+        // themselves when their share of it is stored and do the body column — which nobody reads before the next step's
+        // normalisation phase, i.e. behind the next hand-off A — under the hand-off's latency.  (The partials are double
+        // buffered by step parity for that: a fast member's next fine phase writes partials while a slow one still reads the
+        // body column's.)
+        constexpr int CH = (N + MEMBERS - 1) / MEMBERS;
         constexpr int NIT = (CH + T - 1) / T;
-        static_assert(NIT <= 4, "a few items per thread at most");
-        const int ibase = m * CH, icount = (2 * N - ibase) < CH ? (2 * N - ibase) : CH;
-        double v_[NIT][SK], cqv[NIT], cbv[NIT];
-        // the step's input at these coefficients first (loads only, nothing used yet: the sums below wait for their own loads,
-        // and a load issued behind that wait would be a second round trip)
+        static_assert(NIT <= 2, "one or two coefficients per thread and column");
+        const int ibase = m * CH, icount = (N - ibase) < CH ? (N - ibase > 0 ? N - ibase : 0) : CH;
+        auto norm_share = [&](const int nco) {
+            double v_[NIT][SK], cqv[NIT], cbv[NIT];
+            // the step's input at these coefficients first (loads only, nothing used yet: the sums below wait for their own
+            // loads, and a load issued behind that wait would be a second round trip)
 #pragma unroll
-        for (int u = 0; u < NIT; u++) {
-            cqv[u] = 0.0;                      // TRACE: Y of the step's input at this coefficient (the `+ x` of the trace step)
-            cbv[u] = 0.0;                      // TRACE, body column: Y of the input's body where phi_g takes this coefficient from
-        }
-        if constexpr (!EP) {
-            if (first) {
-#pragma unroll
-                for (int u = 0; u < NIT; u++) {
-                    const int item = ibase + tid + u * T;
-                    const bool on = tid + u * T < icount;
-                    const int nco = on ? item / N : 0, i = on ? item % N : 0;
-                    cqv[u] = raw_double(nco, i);
-                    if (nco == 0) cbv[u] = raw_double(0, (i * ginv) & (N - 1));
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < NIT; u++) {
-                    const int item = ibase + tid + u * T;
-                    const bool on = tid + u * T < icount;
-                    const int nco = on ? item / N : 0, i = on ? item % N : 0;
-                    cqv[u] = ld_l2(yin + (long)nco * N + i);
-                    const double t = ld_l2(yin + ((i * ginv) & (N - 1)));   // column 0; unused (but harmless) for a mask-column item
-                    cbv[u] = (nco == 0) ? t : 0.0;
-                }
+            for (int u = 0; u < NIT; u++) {
+                cqv[u] = 0.0;                  // TRACE: Y of the step's input at this coefficient (the `+ x` of the trace step)
+                cbv[u] = 0.0;                  // TRACE, body column: Y of the input's body where phi_g takes this coefficient from
             }
-        }
+            if constexpr (!EP) {
+                if (first) {
 #pragma unroll
-        for (int u = 0; u < NIT; u++) {
-            const int item = ibase + tid + u * T;
-            const bool on = tid + u * T < icount;
-            const int nco = on ? item / N : 0, i = on ? item % N : 0;
-            const double* bgp = bigg + (long)nco * SK * RS * N + i;
+                    for (int u = 0; u < NIT; u++) {
+                        const int i = (tid + u * T < icount) ? ibase + tid + u * T : 0;
+                        cqv[u] = raw_double(nco, i);
+                        if (nco == 0) cbv[u] = raw_double(0, (i * ginv) & (N - 1));
+                    }
+                } else {
 #pragma unroll
-            for (int q = 0; q < SK; q++) {
-                v_[u][q] = ld_l2(bgp + (long)(q * RS) * N);
-#pragma unroll
-                for (int w = 1; w < RS; w++) v_[u][q] += ld_l2(bgp + (long)(q * RS + w) * N);   // exact: integers below 2^50
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NIT; u++) {
-            const int item = ibase + tid + u * T;
-            if (tid + u * T >= icount) break;
-            const int nco = item / N, i = item % N;
-            double cq = cqv[u], cb = cbv[u];
-            const bool ngb = ((i * ginv) & (2 * N - 1)) >= N;   // phi_g: X^N = -1
-            double carry = 0.0, ad = 0.0;
-            int dig[SO];
-#pragma unroll
-            for (int q = SK - 1; q >= 0; q--) {
-                double v = v_[u][q];
-                if constexpr (!EP) {
-                    if (q < SX) {
-                        v += (q > 0) ? take_digit(cq) : cq;
-                        // vec_znx_big_add_small_inplace of body limb q, seen through phi_g (column 0 only: cb = 0 otherwise)
-                        const double db = (q > 0) ? take_digit(cb) : cb;
-                        v += ngb ? -db : db;
+                    for (int u = 0; u < NIT; u++) {
+                        const int i = (tid + u * T < icount) ? ibase + tid + u * T : 0;
+                        cqv[u] = ld_l2(yin + (long)nco * N + i);
+                        if (nco == 0) cbv[u] = ld_l2(yin + ((i * ginv) & (N - 1)));
                     }
                 }
-                v += carry;
-                const double cy = carry_of(v);
-                carry = cy;
-                if (q < SO) {
-                    const double d = digit_of(v, cy);
-                    dig[q < SO ? q : 0] = (int)d;
-                    ad = __builtin_fma(d, (q == 2) ? 1.0 : ((q == 1) ? TWO_B : TWO_2B), ad);
+            }
+#pragma unroll
+            for (int u = 0; u < NIT; u++) {
+                const int i = (tid + u * T < icount) ? ibase + tid + u * T : 0;
+                const double* bgp = bigg + (long)nco * SK * RS * N + i;
+#pragma unroll
+                for (int q = 0; q < SK; q++) {
+                    v_[u][q] = ld_l2(bgp + (long)(q * RS) * N);
+#pragma unroll
+                    for (int w = 1; w < RS; w++) v_[u][q] += ld_l2(bgp + (long)(q * RS + w) * N);   // exact: integers below 2^50
                 }
             }
-            if (last) {
 #pragma unroll
-                for (int q = 0; q < SO; q++) op[glwe_off(q, nco) + i] = dig[q];
-            } else {
-                yout[(long)nco * N + i] = EP ? ad : __builtin_floor(__builtin_fma(ad, 0.5, 0.5));
+            for (int u = 0; u < NIT; u++) {
+                if (tid + u * T >= icount) break;
+                const int i = ibase + tid + u * T;
+                double cq = cqv[u], cb = cbv[u];
+                const bool ngb = ((i * ginv) & (2 * N - 1)) >= N;   // phi_g: X^N = -1
+                double carry = 0.0, ad = 0.0;
+                int dig[SO];
+#pragma unroll
+                for (int q = SK - 1; q >= 0; q--) {
+                    double v = v_[u][q];
+                    if constexpr (!EP) {
+                        if (q < SX) {
+                            v += (q > 0) ? take_digit(cq) : cq;
+                            // vec_znx_big_add_small_inplace of body limb q, seen through phi_g (column 0 only: cb = 0 otherwise)
+                            const double db = (q > 0) ? take_digit(cb) : cb;
+                            v += ngb ? -db : db;
+                        }
+                    }
+                    v += carry;
+                    const double cy = carry_of(v);
+                    carry = cy;
+                    if (q < SO) {
+                        const double d = digit_of(v, cy);
+                        dig[q < SO ? q : 0] = (int)d;
+                        ad = __builtin_fma(d, (q == 2) ? 1.0 : ((q == 1) ? TWO_B : TWO_2B), ad);
+                    }
+                }
+                if (last) {
+#pragma unroll
+                    for (int q = 0; q < SO; q++) op[glwe_off(q, nco) + i] = dig[q];
+                } else {
+                    yout[(long)nco * N + i] = EP ? ad : __builtin_floor(__builtin_fma(ad, 0.5, 0.5));
+                }
             }
+        };
+        norm_share(1);
+        if (last) {
+            norm_share(0);
+            MSTAMP(5);
+        } else if constexpr (EP) {             // a product's next fine phase reads both columns
+            norm_share(0);
+            MSTAMP(5);
+            if (!mid_barrier(ctr, (++epoch) * MEMBERS, flag, tid)) break;
+        } else {
+            mid_arrive(ctr, tid);
+            norm_share(0);
+            MSTAMP(5);
+            if (!mid_wait(ctr, (++epoch) * MEMBERS, flag, tid)) break;
         }
-        MSTAMP(5);
-        if (!last && !mid_barrier(ctr, (++epoch) * MEMBERS, flag, tid)) break;
         MSTAMP(6);
     }
     // the last workgroup of the group to leave (every one passes here exactly once, given up or not) records whether the

@@ -136,7 +136,7 @@ int use_mid(const fheram_ctx* c, int n, int gx, int gy, int sk, bool ep = false)
 template <bool EP>
 void fill_mid(fheram_ctx* c, MidArgs& ma, GlweRef src, GlweRef dst, int n, int gx, int gy) {
     const int side = c->cur == c->stream2 ? 1 : 0;
-    ma.src = src; ma.dst = dst; ma.tw = c->d_tw; ma.big = big_of(c); ma.sync = c->d_mid_sync[side]; ma.y = c->d_mid_y[side];
+    ma.src = src; ma.dst = dst; ma.tw = c->d_tw; ma.big = c->d_mid_big[side]; ma.sync = c->d_mid_sync[side]; ma.y = c->d_mid_y[side];
     if (++c->mid_seq == 0) ++c->mid_seq;
     c->mid_launches++;
     if (!c->mid_test && c->mid_launches - c->mid_launch_mark >= 64) {   // as the tail: a context that keeps losing its CUs to others stops asking
