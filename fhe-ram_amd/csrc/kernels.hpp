@@ -1203,6 +1203,26 @@ __device__ __forceinline__ bool tail_barrier(unsigned* ctr, unsigned* abortp, un
     __syncthreads();
     return *flag != 0;
 }
+// The same in two halves (see k_chain_mid): announce the arrival, go on with work nobody waits for, wait later.
+__device__ __forceinline__ void tail_arrive(unsigned* ctr, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool tail_wait(unsigned* ctr, unsigned* abortp, unsigned seq, unsigned want, int* flag, int tid) {
+    if (tid == 0) {
+        int ok = 0;
+        for (int spin = 0; spin < TAIL_SPIN_MAX; spin++) {
+            if ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) { ok = 1; break; }
+            if ((spin & 15) == 15 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) break;
+        }
+        if (ok && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) ok = 0;
+        if (!ok) __hip_atomic_store(abortp, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
 // Two int32 per 8-byte L1-bypassing load (coefficients 2q, 2q+1 of one limb polynomial).
 __device__ __forceinline__ void ld_l2_pair(const int32_t* p, int& a, int& b) {
     const long long v = __hip_atomic_load(reinterpret_cast<long long*>(const_cast<int32_t*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1231,7 +1251,7 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
     const int j = SK - 1 - zz % SK, co = zz / SK;
     const long ct = (long)(g / ta.gx);
     const long cx = (long)(g % ta.gx);
-    double* bigg = ta.big + (long)g * BIG_STRIDE * SX;
+    double* const big0 = ta.big + (long)g * BIG_STRIDE * SX;   // + step parity * TAIL_GROUPS * BIG_STRIDE * SX (see the normalisation phase)
     OpRegs kop;
     load_ops(kop, ta.key[0] + (long)((r * SK + j) * 2 + co) * N, tid);
     if (tid == 0) {
@@ -1249,6 +1269,7 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
         const int ginv = ta.ginv[s];
         const bool stepped = (s > 0);          // the input already is rsh1(a)
         const bool last = (s + 1 == ta.n);
+        double* const bigg = big0 + (long)(s & 1) * TAIL_GROUPS * BIG_STRIDE * SX;
         TSTAMP(0);
         // ---- fine phase: x = rsh1(a); partial[co][j][r] = INTT(NTT(phi_g(x.mask limb r)) . K[r][j][co]) (+ phi_g(x.body limb j))
         // staging: thread t brings coefficients 8t .. 8t+7 (natural order) of the limb polynomials it needs
@@ -1311,59 +1332,72 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
         if (!tail_barrier(ctr, abortp, ta.seq, (++epoch) * G, flag, s == 0, tid)) break;
         TSTAMP(5);
         // ---- normalisation phase: one thread per (column, coefficient); same arithmetic as k_keyswitch_norm<KS_TRACE>.
-        // Every member takes an equal share of the 2N coefficients (CH consecutive ones: the phase is as long as its busiest
-        // member's L2 reads; with T per member a third of the members had none)
-        constexpr int CH = (2 * N + G - 1) / G;
-        static_assert(CH <= T, "one coefficient per thread");
-        const int gid = m * CH + tid;
-        if (tid < CH && gid < 2 * N) {
-            const int nco = gid / N, i = gid % N;
-            const double* bgp = bigg + (long)nco * SK * SX * N + i;
-            double v_[SK];
+        // Every member takes an equal share of each column (CH consecutive coefficients: the phase is as long as its busiest
+        // member's L2 reads; with T per member a third of the members had none).  The next fine phase needs the mask column
+        // only: the members announce themselves when their share of it is stored and do the body column under the hand-off's
+        // latency (nobody reads it before the next normalisation phase; the partials are double buffered by step parity for
+        // that, see k_chain_mid).
+        constexpr int CH = (N + G - 1) / G;
+        static_assert(CH <= T, "one coefficient per thread and column");
+        auto norm_share = [&](const int nco) {
+            const int i = m * CH + tid;
+            if (tid < CH && i < N) {
+                const double* bgp = bigg + (long)nco * SK * SX * N + i;
+                double v_[SK];
 #pragma unroll
-            for (int q = 0; q < SK; q++) {
-                v_[q] = ld_l2(bgp + (long)(q * SX) * N);
+                for (int q = 0; q < SK; q++) {
+                    v_[q] = ld_l2(bgp + (long)(q * SX) * N);
 #pragma unroll
-                for (int w = 1; w < SX; w++) v_[q] += ld_l2(bgp + (long)(q * SX + w) * N);   // exact: integers below 2^47
+                    for (int w = 1; w < SX; w++) v_[q] += ld_l2(bgp + (long)(q * SX + w) * N);   // exact: integers below 2^47
+                }
+                int raw[SX], xa[SX];
+#pragma unroll
+                for (int q = 0; q < SX; q++) raw[q] = ld_l2(ap + glwe_off(q, nco) + i);
+                // vec_znx_big_add_small_inplace of the body column seen through phi_g (column 0 only): it joins the sums here,
+                // where every member has the same share of it, instead of lengthening the fine phase of the three members that owned it
+                const int si = (i * ginv) & (2 * N - 1);
+                int braw[SX], xb[SX];
+#pragma unroll
+                for (int q = 0; q < SX; q++) braw[q] = (nco == 0) ? ld_l2(ap + glwe_off(q, 0) + (si & (N - 1))) : 0;
+                if (stepped) {
+#pragma unroll
+                    for (int q = 0; q < SX; q++) { xa[q] = raw[q]; xb[q] = braw[q]; }
+                } else {
+                    rsh1_coeff<SX>(raw, xa);
+                    rsh1_coeff<SX>(braw, xb);
+                }
+                double carry = 0.0;
+                int d[SO], y[SO];
+#pragma unroll
+                for (int q = SK - 1; q >= 0; q--) {
+                    double v = v_[q];
+                    if (q < SX) v += (double)xa[q < SX ? q : 0] + (double)cneg(xb[q < SX ? q : 0], si >= N);
+                    v += carry;
+                    const double cy = carry_of(v);
+                    carry = cy;
+                    if (q < SO) d[q < SO ? q : 0] = (int)digit_of(v, cy);
+                }
+                if (last) {
+#pragma unroll
+                    for (int q = 0; q < SO; q++) y[q] = d[q];
+                } else {
+                    rsh1_coeff<SO>(d, y);
+                }
+#pragma unroll
+                for (int q = 0; q < SO; q++) op[glwe_off(q, nco) + i] = y[q];
             }
-            int raw[SX], xa[SX];
-#pragma unroll
-            for (int q = 0; q < SX; q++) raw[q] = ld_l2(ap + glwe_off(q, nco) + i);
-            // vec_znx_big_add_small_inplace of the body column seen through phi_g (column 0 only): it joins the sums here, where
-            // every member has the same share of it, instead of lengthening the fine phase of the three members that owned it
-            const int si = (i * ginv) & (2 * N - 1);
-            int braw[SX], xb[SX];
-#pragma unroll
-            for (int q = 0; q < SX; q++) braw[q] = (nco == 0) ? ld_l2(ap + glwe_off(q, 0) + (si & (N - 1))) : 0;
-            if (stepped) {
-#pragma unroll
-                for (int q = 0; q < SX; q++) { xa[q] = raw[q]; xb[q] = braw[q]; }
-            } else {
-                rsh1_coeff<SX>(raw, xa);
-                rsh1_coeff<SX>(braw, xb);
-            }
-            double carry = 0.0;
-            int d[SO], y[SO];
-#pragma unroll
-            for (int q = SK - 1; q >= 0; q--) {
-                double v = v_[q];
-                if (q < SX) v += (double)xa[q < SX ? q : 0] + (double)cneg(xb[q < SX ? q : 0], si >= N);
-                v += carry;
-                const double cy = carry_of(v);
-                carry = cy;
-                if (q < SO) d[q < SO ? q : 0] = (int)digit_of(v, cy);
-            }
-            if (last) {
-#pragma unroll
-                for (int q = 0; q < SO; q++) y[q] = d[q];
-            } else {
-                rsh1_coeff<SO>(d, y);
-            }
-#pragma unroll
-            for (int q = 0; q < SO; q++) op[glwe_off(q, nco) + i] = y[q];
+        };
+        norm_share(1);
+        if (last) {
+            norm_share(0);
+            TSTAMP(6);
+        } else {
+            tail_arrive(ctr, tid);
+            norm_share(0);
+            TSTAMP(6);
+            ++epoch;
+            if (!tail_wait(ctr, abortp, ta.seq, epoch * G, flag, tid)) break;
         }
-        TSTAMP(6);
-        if (!last && !tail_barrier(ctr, abortp, ta.seq, (++epoch) * G, flag, false, tid)) break;
         TSTAMP(7);
     }
     // the last workgroup of the group to leave (every one passes here exactly once, given up or not) rewinds the
