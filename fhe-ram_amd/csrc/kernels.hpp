@@ -135,31 +135,39 @@ __device__ __forceinline__ void gstore_i32(int32_t* base, unsigned byte_off, int
 }
 
 // ---------------------------------------------------------------------------------------
-// k_prepare: forward transform of `npoly` small polynomials into prepared form.
+// k_prepare: forward transform of `npoly` small polynomials into prepared form.  One transform at a time: the twiddle table and
+// ONE exchange buffer of LDS (LDS_PREPARE_BYTES), so that two workgroups share a CU and the 288 polynomials of an address
+// (6 digits at 2^18) are one round of workgroups on 256 CUs instead of two.
 // ginv != 0: the polynomial is first mapped through phi_g (g = ginv^-1 mod 2N), i.e. the prepared
 // operand is NTT(phi_g(K)).  Automorphism keys are stored this way so that the key-switch can apply
 // phi_g to its INPUT instead of to every output limb:  phi_g(sum_r x_r * K_r) = sum_r phi_g(x_r) * phi_g(K_r).
 // ---------------------------------------------------------------------------------------
+constexpr size_t LDS_PREPARE_BYTES = (size_t)(LDS_TW + LDS_DATA) * sizeof(double);
 __global__ __launch_bounds__(T) void k_prepare(const int32_t* __restrict__ in, double* __restrict__ out,
                                                const double* __restrict__ tw_g, double ninv, int ginv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = threadIdx.x;
-    load_twiddles(tw, tw_g, tid);
+    TwRegs twr;
+    twiddles_issue(twr, tw_g, tid);            // the table and the polynomial in ONE round trip (the commit's barrier comes after both)
     const int32_t* src = in + (long)blockIdx.x * N;
-    double x[1][E];
+    int v[E];
     if (ginv == 0) {
 #pragma unroll
-        for (int k = 0; k < E; k++) x[0][k] = (double)src[tid + T * k];
+        for (int k = 0; k < E; k++) v[k] = src[tid + T * k];
     } else {   // destination i' takes +-source i, i = i' * ginv mod 2N (one-off gather at key load)
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const int s = ((tid + T * k) * ginv) & (2 * N - 1);
-            const int v = src[s & (N - 1)];
-            x[0][k] = (double)(s >= N ? -v : v);
+            const int w = src[s & (N - 1)];
+            v[k] = s >= N ? -w : w;
         }
     }
+    twiddles_commit(twr, tw, tid);
+    double x[1][E];
+#pragma unroll
+    for (int k = 0; k < E; k++) x[0][k] = (double)v[k];
     ntt_fwd<1>(x, tw, data, tid);
     double2* o = reinterpret_cast<double2*>(out + (long)blockIdx.x * N);
 #pragma unroll

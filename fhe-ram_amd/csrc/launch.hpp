@@ -18,7 +18,7 @@ int pick_nco(const fheram_ctx* c, int gx, int gy) {
 void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly, int64_t gal = 0) {
     ProfScope ps(c, "prepare", npoly);
     const int ginv = gal == 0 ? 0 : galois_inv_mod(galois_mod(gal));
-    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_BYTES, c->cur, in, out, c->d_tw, c->ninv, ginv);
+    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_PREPARE_BYTES, c->cur, in, out, c->d_tw, c->ninv, ginv);
 }
 // res = a (x) ggsw over a (gx, gy) grid of ciphertexts; res must not alias a
 // Limb-parallel path: 2*SK workgroups per ciphertext + a normalisation pass, chosen while even the
