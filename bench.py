@@ -507,7 +507,7 @@ def main():
                                       "gave up (CUs not available side by side) and were redone by the fused launch behind them"),
         "device": ram.device_info(),
     }
-    out["mid_chain"] = dict(mid, note="dependent chains on 9..16 ciphertexts (MAX_ADDR 2^13, 2^14) as one launch with in-kernel hand-offs (k_chain_mid)")
+    out["mid_chain"] = dict(mid, note="dependent chains on 9..64 ciphertexts (MAX_ADDR 2^14..2^16) as one launch with in-kernel hand-offs (k_chain_mid); fallbacks = ciphertexts redone by the launch behind")
     if tail["fallbacks"] > 0 or mid["fallbacks"] > 0:
         out["trace_tail_degraded"] = True     # silent degradation made visible: some single-launch chains were redone by their fallback
         print(f"bench.py: WARNING: {tail['fallbacks']} of {tail['launches']} single-launch trace chains fell back", file=sys.stderr)

@@ -829,7 +829,7 @@ class Ram:
         return {"launches": int(a.value), "fallbacks": int(b.value)}
 
     def mid_stats(self):
-        """single-launch chains on 9..16 ciphertexts since the context was created, and how many ciphertexts were redone by the launch behind (fheram_mid_stats)"""
+        """single-launch chains on 9..64 ciphertexts since the context was created, and how many ciphertexts were redone by the launch behind (fheram_mid_stats)"""
         a, b = C.c_uint64(), C.c_uint64()
         self._chk(library().fheram_mid_stats(self._h, C.byref(a), C.byref(b)))
         return {"launches": int(a.value), "fallbacks": int(b.value)}

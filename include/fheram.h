@@ -287,8 +287,8 @@ int fheram_profile_reset(fheram_ctx* ctx);
  * launch enqueued behind it redoes the chain, with the same result.  launches = such launches since the context was
  * created, fallbacks = how many of them gave up.  Waits for the context's stream. */
 int fheram_tail_stats(fheram_ctx* ctx, uint64_t* launches, uint64_t* fallbacks);
-/* The same for the dependent chains on 9..16 ciphertexts (the alone packer levels, CoordinatePrepared::product[_inplace]
- * and write_mid_step's traces at MAX_ADDR = 2^13, 2^14 — the source default), which run as one launch with in-kernel
+/* The same for the dependent chains on 9..64 ciphertexts (the alone packer levels, CoordinatePrepared::product[_inplace]
+ * and write_mid_step's traces at MAX_ADDR = 2^14 — the source default — to 2^16), which run as one launch with in-kernel
  * hand-offs too (k_chain_mid).  Each ciphertext's workgroups stand alone there: fallbacks = CIPHERTEXTS redone by the fused
  * launch behind (0 on a GPU the context has to itself). */
 int fheram_mid_stats(fheram_ctx* ctx, uint64_t* launches, uint64_t* fallbacks);
