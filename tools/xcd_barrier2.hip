@@ -7,6 +7,9 @@
 //   V 3: as 0, but every WAVE drains its own stores and arrives by itself (8 arrivals per workgroup, no workgroup barrier
 //        in front of the arrival)
 //   V 4: no data hand-off at all (barriers only): the cost of the two meetings alone
+//   V 5: no meeting at all: the data carry a 2-bit round tag (v * 4 + tag, exact for integers below 2^50), the producer just
+//        stores, the consumer polls its 8 values until every tag is the round's; the second meeting of a round (consumer done
+//        before the producer overwrites) is replaced by double buffering on the round's parity
 //   hipcc -O3 --offload-arch=gfx950 -o tools/xcd_barrier2 tools/xcd_barrier2.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -39,6 +42,35 @@ __device__ __forceinline__ void meet(unsigned* ctr, unsigned* go, unsigned want_
         }
     }
     __syncthreads();
+}
+__global__ __launch_bounds__(T) void k_tagged(double* buf, unsigned* errors, int G, int groups, int rounds) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x;
+    const int g = b % NXCD, m = b / NXCD;
+    if (g >= groups || m >= G) return;
+    lds[threadIdx.x] = 0.0;
+    unsigned bad = 0;
+    for (int r = 0; r < rounds; r++) {
+        double* mine = buf + (((size_t)(r & 1) * NXCD + g) * G + m) * POLY;
+        const double* theirs = buf + (((size_t)(r & 1) * NXCD + g) * G + (m + 1) % G) * POLY;
+        const double tag = (double)((r + 1) & 3);
+#pragma unroll
+        for (int k = 0; k < E; k++) mine[threadIdx.x + T * k] = ((double)(r * 7 + m * 3 + k) + lds[threadIdx.x]) * 4.0 + tag;
+        const double expect0 = (double)(r * 7 + ((m + 1) % G) * 3);
+        double v[E];
+        for (int spin = 0; spin < (1 << 20); spin++) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < E; k++) v[k] = __hip_atomic_load(theirs + threadIdx.x + T * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < E; k++) { const double q = __builtin_floor(v[k] * 0.25); ok = ok && (v[k] - 4.0 * q == tag); v[k] = q; }
+            if (__all(ok)) break;     // wave-uniform exit: the whole wave polls again while any lane is stale
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) bad += (v[k] != expect0 + k);
+        __syncthreads();   // stands for the workgroup-level dependency of the real kernel (transform across waves)
+    }
+    if (bad) atomicAdd(errors, bad);
 }
 template <int V>
 __global__ __launch_bounds__(T) void k_rounds(double* buf, unsigned* counters, unsigned* errors, int G, int groups, int rounds) {
@@ -91,6 +123,27 @@ void run(const char* name, int G, int groups, int rounds) {
     printf("%-66s G=%2d groups=%d: %.2f us per round, errors %u\n", name, G, groups, best * 1e3 / rounds, herr);
     hipFree(buf); hipFree(ctr); hipFree(err);
 }
+void run_tagged(int G, int groups, int rounds) {
+    const int grid = G * NXCD;
+    double* buf; unsigned* err;
+    hipMalloc(&buf, (size_t)2 * NXCD * G * POLY * 8); hipMalloc(&err, 4);
+    hipFuncSetAttribute((const void*)k_tagged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9f;
+    unsigned herr = 0;
+    for (int rep = 0; rep < 5; rep++) {
+        hipMemset(buf, 0, (size_t)2 * NXCD * G * POLY * 8); hipMemset(err, 0, 4);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k_tagged, dim3(grid), dim3(T), LDS, 0, buf, err, G, groups, rounds);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+        unsigned e; hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost); herr += e;
+    }
+    printf("%-66s G=%2d groups=%d: %.2f us per round, errors %u\n", "V5 tagged data, no meeting (ONE hand-off per round, double buffered)", G, groups, best * 1e3 / rounds, herr);
+    hipFree(buf); hipFree(err);
+}
 int main() {
     const int rounds = 400;
     for (int groups : {4, 8})
@@ -100,6 +153,7 @@ int main() {
             run<2>("V2 last arriver writes a go word in another line, polls go there", G, groups, rounds);
             run<3>("V3 every wave arrives by itself", G, groups, rounds);
             run<4>("V4 the two meetings alone (no data)", G, groups, rounds);
+            run_tagged(G, groups, rounds);
         }
     return 0;
 }
