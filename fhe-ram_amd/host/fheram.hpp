@@ -138,6 +138,11 @@ public:
         chk(fheram_write(ctx_, flat.data(), (int)w.size(), dev(address)));
     }
     bool state() const { return fheram_ram_state(ctx_) != 0; }                    // SubRam::state, ram.rs:302
+    // Health of the single-launch chains (in-kernel hand-offs): how many were launched and how many gave up and were redone by
+    // the launch behind them (0 on a GPU this context has to itself; INTEGRATION.md, "Sharing a GPU")
+    struct ChainStats { uint64_t launches = 0, redone = 0; };
+    ChainStats tail_stats() { ChainStats s; chk(fheram_tail_stats(ctx_, &s.launches, &s.redone)); return s; }
+    ChainStats mid_stats() { ChainStats s; chk(fheram_mid_stats(ctx_, &s.launches, &s.redone)); return s; }
     // The result of the last read / read_prepare_write where the device left it: [word_size][GLWE] int64 in the context's
     // pinned host buffer (no copy on the host); valid until the next operation on this Ram.
     const int64_t* result_view() {

@@ -45,6 +45,8 @@ int main() {
                 for (size_t k = 0; k < r[i].size(); k++)
                     if (v[i * r[i].size() + k] != r[i][k]) { std::printf("result_view differs\n"); return 7; }
             std::printf("result in place == result copied: ok\n");
+            const auto ts = ram.tail_stats();
+            if (ts.launches == 0 || ts.redone != 0) { std::printf("tail stats: %llu launches, %llu redone\n", (unsigned long long)ts.launches, (unsigned long long)ts.redone); return 10; }
         }
         // Address::set_from_fheuint (conversion.rs:68-82): the same word through an address derived from an encrypted integer
         fheram::Ram::FheUintPrepared fu(ram, idx, dsk, xa, xe, 12);
