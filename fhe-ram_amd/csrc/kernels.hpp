@@ -45,6 +45,9 @@ __device__ unsigned long long g_stamps[192];
 #ifndef FK_STAMP_STEP
 #define FK_STAMP_STEP 2
 #endif
+#ifndef FK_STAMP_STEP_Y
+#define FK_STAMP_STEP_Y 3
+#endif
 // k_trace_tail: every member of group 0, step FK_STAMP_STEP: g_stamps[stamp * 24 + member], 100 MHz real-time clock (the same on every CU)
 #define TSTAMP(i)                                                                                  \
     do {                                                                                           \
@@ -67,7 +70,21 @@ __device__ unsigned long long g_stamps[192];
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
+// ks_trace_y inside a chain launch: wave 0 of workgroup (0,0,0), step FK_STAMP_STEP of the chain
+#define YSTAMP(i)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (stamp_on && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                  \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            g_stamps[i] = t_;                                                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define YSTAMP_STEP(i) ((i) == FK_STAMP_STEP_Y)
 #else
+#define YSTAMP_STEP(i) false
+#define YSTAMP(i) do { } while (0)
 #define STAMP(i) do { } while (0)
 #define STAMPZ(i) do { } while (0)
 #define TSTAMP(i) do { } while (0)
@@ -247,6 +264,17 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #ifndef FK_EARLY_FETCH
 #define FK_EARLY_FETCH 0
 #endif
+#ifndef FK_SPREAD_FETCH
+#define FK_SPREAD_FETCH 1      // ks_trace_y: the next limb's operand loads spread over the post-step (38.8 against 39.7 us per trace step)
+#endif
+#ifndef FK_SPREAD_FETCH_EP
+#define FK_SPREAD_FETCH_EP 0   // the same in ep_run
+#endif
+// Register cap of the chain kernels (see k_keyswitch_chain): one workgroup per CU, two waves per SIMD; above 240 registers the
+// two waves leave no room for the one-wave gate launch of read_prepare_write and the workgroup stays off that CU.
+#ifndef FK_CHAIN_VGPRS
+#define FK_CHAIN_VGPRS 120   // the attribute counts in units of two on gfx90a+ (unified VGPR + AGPR file): 120 -> 240 registers: two waves leave 32 registers of a SIMD for a small third one
+#endif
 static_assert(BF <= BMAX && BI <= BMAX, "LDS holds BMAX exchange buffers");
 
 // forward transform of S polynomials, BF at a time
@@ -405,9 +433,29 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
             ntt_inv<BI, !DB>(acc, tw, data + (DB ? (it++ & 1) * BI * LDS_DATA : 0), tid);
-            if constexpr (FK_EARLY_FETCH == 0) { if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid); }   // overlaps the normalisation step
+            if constexpr (FK_EARLY_FETCH == 0 && FK_SPREAD_FETCH_EP && BI == 1) {   // measured: 51.9 against 50.9 us per product (247 registers: over the cap, six spills): off
+                // the next limb's column_in 0 operands, one polynomial at a time between the parts of the normalisation step (see
+                // ks_trace_y: twelve loads per thread from all waves at once wait for the address unit)
+                const bool more = j - BI >= 0;
+                const int jn = j - BI;
+                auto fetch1 = [&](int r) { if (more) load_ops(g[r], ggsw + (long)(((2 * r) * SG + jn) * 2 + co) * N, tid); };
+                fetch1(0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int b = 0; b < BI; b++) emit(acc[b], j - b);
+                for (int k = 0; k < E; k++) {
+                    if (SA > 1 && k == E / 4) { __builtin_amdgcn_sched_barrier(0); fetch1(1); __builtin_amdgcn_sched_barrier(0); }
+                    if (SA > 2 && k == (3 * E) / 4) { __builtin_amdgcn_sched_barrier(0); fetch1(2); __builtin_amdgcn_sched_barrier(0); }
+                    const double v = acc[0][k] + carry[k];
+                    const double cy = carry_of(v);
+                    carry[k] = cy;
+                    if (j < SA) gstore_i32(rp + glwe_off(j, co), (unsigned)(tid + T * k) * 4u, (int)digit_of(v, cy));
+                }
+                static_assert(SA <= 3, "three operand polynomials per half");
+            } else {
+                if constexpr (FK_EARLY_FETCH == 0) { if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid); }   // overlaps the normalisation step
+#pragma unroll
+                for (int b = 0; b < BI; b++) emit(acc[b], j - b);
+            }
         }
         if constexpr (REM == 1) {
             double acc[1][E];
@@ -443,7 +491,7 @@ struct EpChainArgs {
     unsigned* host_count = nullptr;  // pinned host word that mirrors the number of ciphertexts redone (read by the host without a sync)
 };
 template <int SA, int SG>
-__global__ __launch_bounds__(T, T / 256) void k_ext_product_chain(EpChainArgs ca) {
+__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_ext_product_chain(EpChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.done) {
         if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
@@ -936,7 +984,8 @@ __device__ __forceinline__ double take_digit(double& c) {
     return d;
 }
 template <int SK, bool IN_Y, bool OUT_Y>
-__device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool load_tw, const int tid) {
+__device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool load_tw, const int tid, const bool stamp_on = false) {
+    YSTAMP(0);
     constexpr int SX = 3, SO = 3;
     double* tw = lds;
     double* data = lds + LDS_TW;
@@ -974,6 +1023,7 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
     }
 #pragma unroll
     for (int k = 0; k < E; k++) ystage[tid + T * k] = y1[k];
+    YSTAMP(1);
     if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();   // its barrier also publishes the staged column
 
     // Phase 1: the digits of the mask column seen through phi_g, transformed
@@ -993,16 +1043,19 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
             sidx = (sidx + sstep) & (2 * N - 1);
         }
     }
+    YSTAMP(2);
     fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before buffer 0 is overwritten
 
     // the body column, staged for the gathers of add_body — and parked there: its owner takes it back when its turn comes,
     // so that only ONE column's Y is held in registers during the limb loops (the mask column goes first, from the registers
     // it already is in)
+    YSTAMP(3);
     lds_barrier();                     // slower waves may still be inside the wave-local exchanges of the forward transforms
 #pragma unroll
     for (int k = 0; k < E; k++) bstage[tid + T * k] = y0[k];
     // published by the barriers of the first inverse transform, which precede every gather
 
+    YSTAMP(4);
     int it = 0;
 #pragma unroll 1
     for (int ci = 0; ci < 2; ci++) {
@@ -1023,7 +1076,8 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
 #pragma unroll
             for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
         };
-        fetch(SK - 1);
+        fetch(SK - 1);   // (requested earlier the operand registers spill — in front of the forward transforms, or column 0's during
+                         // column 1's last post-step: 45 us per step — or change nothing: behind the forward transforms)
 #pragma unroll 1
         for (int j = SK - 1; j >= 0; j--) {
             double acc[1][E];
@@ -1031,9 +1085,18 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
             for (int k = 0; k < E; k++) acc[0][k] = 0.0;
 #pragma unroll
             for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
+            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
             __builtin_amdgcn_sched_barrier(0);
-            ntt_inv<1, false, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);   // 3 MAC terms: no initial reduction; double-buffered exchanges
-            if (j >= 1) fetch(j - 1);                                                // next limb's operands: their latency overlaps the post-step
+            ntt_inv<1, false, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);
+            YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);   // 3 MAC terms: no initial reduction; double-buffered exchanges
+            // next limb's operands: their latency overlaps the post-step.  One operand polynomial at a time, between the parts
+            // of the post-step (FK_SPREAD_FETCH): 12 loads per thread from all eight waves at once wait for the address unit
+            // to take them (16 cycles per wave and load), and a wave that waits there computes nothing
+            auto fetch_next = [&](int r) {
+                if (j >= 1) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
+            };
+            if constexpr (FK_SPREAD_FETCH) fetch_next(0); else { if (j >= 1) fetch(j - 1); }
+            __builtin_amdgcn_sched_barrier(0);
             if (co == 0 && j < SX) {   // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
                 int sidx = sidx0;
 #pragma unroll
@@ -1046,9 +1109,14 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
                     sidx = (sidx + sstep) & (2 * N - 1);
                 }
             }
+            YSTAMP(10 + (ci * SK + (SK - 1 - j)) * 4);
             const double scale = (j == 2) ? 1.0 : ((j == 1) ? TWO_B : TWO_2B);
 #pragma unroll
             for (int k = 0; k < E; k++) {
+                if constexpr (FK_SPREAD_FETCH) {
+                    if (k == E / 4) { __builtin_amdgcn_sched_barrier(0); fetch_next(1); __builtin_amdgcn_sched_barrier(0); }
+                    if (k == (3 * E) / 4) { __builtin_amdgcn_sched_barrier(0); fetch_next(2); __builtin_amdgcn_sched_barrier(0); }
+                }
                 double v = acc[0][k];
                 if (j < SX) {          // a + phi(KS(a)): limb j of rsh1(a) = digit j of Y
                     const double xl = (j > 0) ? take_digit(cq[k]) : cq[k];
@@ -1063,6 +1131,7 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
                     else gstore_i32(op + glwe_off(j, co), (unsigned)(tid + T * k) * 4u, (int)d);
                 }
             }
+            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         }
         if constexpr (OUT_Y) {
             double* yo = reinterpret_cast<double*>(op) + (long)co * N;
@@ -1070,6 +1139,7 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
             for (int k = 0; k < E; k++) gstore_f64(yo, (unsigned)(tid + T * k) * 8u, __builtin_floor(__builtin_fma(od[k], 0.5, 0.5)));
         }
     }
+    YSTAMP(5);
 }
 
 // GLWE::trace(start, start + n) (ram.rs:457,540,572,616,621 and the packer levels in which every
@@ -1098,9 +1168,6 @@ struct KsChainArgs {
 // file, and ANY other wave resident on the CU — the one-wave gate launch that read_prepare_write parks on the side stream is
 // enough — keeps the workgroup off that CU: a 256-workgroup launch on 256 CUs then runs in two rounds (+0.24 ms per
 // read_prepare_write, measured when the Y-form kernel first compiled to 250).  Capped so that a small wave still fits.
-#ifndef FK_CHAIN_VGPRS
-#define FK_CHAIN_VGPRS 120   // the attribute counts in units of two on gfx90a+ (unified VGPR + AGPR file): 120 -> 240 registers: two waves leave 32 registers of a SIMD for a small third one
-#endif
 template <int SX, int SK, int SO, bool YF = false>
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1131,7 +1198,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         if constexpr (YF) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y); n >= 2
             static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
             if (i == 0) ks_trace_y<SK, false, true>(ka, lds, true, tid);
-            else if (i + 1 < ca.n) ks_trace_y<SK, true, true>(ka, lds, false, tid);
+            else if (i + 1 < ca.n) ks_trace_y<SK, true, true>(ka, lds, false, tid, YSTAMP_STEP(i));
             else ks_trace_y<SK, true, false>(ka, lds, false, tid);
         } else {
             ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
