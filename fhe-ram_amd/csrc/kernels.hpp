@@ -268,7 +268,7 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #define FK_SPREAD_FETCH 1      // ks_trace_y: the next limb's operand loads spread over the post-step (38.8 against 39.7 us per trace step)
 #endif
 #ifndef FK_SPREAD_FETCH_EP
-#define FK_SPREAD_FETCH_EP 0   // the same in ep_run
+#define FK_SPREAD_FETCH_EP 0   // the same in ep_run (247 registers: over the cap, six spills, 51.9 against 50.9 us per product: off)
 #endif
 // Register cap of the chain kernels (see k_keyswitch_chain): one workgroup per CU, two waves per SIMD; above 240 registers the
 // two waves leave no room for the one-wave gate launch of read_prepare_write and the workgroup stays off that CU.
@@ -440,11 +440,11 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
                 const int jn = j - BI;
                 auto fetch1 = [&](int r) { if (more) load_ops(g[r], ggsw + (long)(((2 * r) * SG + jn) * 2 + co) * N, tid); };
                 fetch1(0);
+                if (SA > 1) fetch1(1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < E; k++) {
-                    if (SA > 1 && k == E / 4) { __builtin_amdgcn_sched_barrier(0); fetch1(1); __builtin_amdgcn_sched_barrier(0); }
-                    if (SA > 2 && k == (3 * E) / 4) { __builtin_amdgcn_sched_barrier(0); fetch1(2); __builtin_amdgcn_sched_barrier(0); }
+                    if (SA > 2 && k == E / 2) { __builtin_amdgcn_sched_barrier(0); fetch1(2); __builtin_amdgcn_sched_barrier(0); }
                     const double v = acc[0][k] + carry[k];
                     const double cy = carry_of(v);
                     carry[k] = cy;

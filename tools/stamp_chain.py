@@ -15,7 +15,7 @@ for rep in range(3):
     L.fheram_debug_stamps(ram._h, st, 192)
     s = np.array([int(x) for x in st], dtype=np.int64)
     t0 = s[0]
-    tick = 10.0   # ns per tick
+    tick = 1.0   # raw ticks (the shader clock: divide by ~2.2 for ns)
     print(f"== rep {rep}: inner step of k_keyswitch_chain<3,4,3,true>, batch 256, wave 0 of workgroup 0; ns since the step began")
     print(f"  Y of both columns loaded, mask column staged  {(s[1]-t0)*tick:8.0f}")
     print(f"  barrier, gather through phi_g, digits         {(s[2]-t0)*tick:8.0f}")
