@@ -267,6 +267,9 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #ifndef FK_SPREAD_FETCH
 #define FK_SPREAD_FETCH 1      // ks_trace_y: the next limb's operand loads spread over the post-step (38.8 against 39.7 us per trace step)
 #endif
+#ifndef FK_EP_PREFETCH
+#define FK_EP_PREFETCH 0       // ep_run: the first output limb's operands of a column requested ahead of the column loop (75 spilled registers: off)
+#endif
 #ifndef FK_SPREAD_FETCH_EP
 #define FK_SPREAD_FETCH_EP 0   // the same in ep_run (247 registers: over the cap, six spills, 51.9 against 50.9 us per product: off)
 #endif
@@ -355,6 +358,7 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
     const int co0 = (NCO == 1) ? (int)blockIdx.z : 0;
 
     double x0[SA][E], x1[SA][E];   // limbs of column 0 / column 1 of a
+    OpRegs gpre[SA];               // operands requested ahead of the column loop (FK_EP_PREFETCH)
     {
         int xi[SA][E];
 #pragma unroll
@@ -375,6 +379,12 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
         for (int r = 0; r < SA; r++)
 #pragma unroll
             for (int k = 0; k < E; k++) x1[r][k] = (double)xi[r][k];
+        if constexpr (STAGE == 0 && FK_EP_PREFETCH) {
+            // the column_in 0 operands of the first output limb of the first column: requested in front of the second batch of
+            // forward transforms (accumulator and carries are not live yet), so that no column starts with an exposed round trip
+#pragma unroll
+            for (int r = 0; r < SA; r++) load_ops(gpre[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co0) * N, tid);
+        }
         fwd_all<SA>(x1, tw, data, tid);
     }
     if constexpr (STAGE == 1) {
@@ -405,8 +415,13 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
 #pragma unroll
         for (int k = 0; k < E; k++) carry[k] = 0.0;
         OpRegs g[SA];
+        if constexpr (STAGE == 0 && FK_EP_PREFETCH) {
 #pragma unroll
-        for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co) * N, tid);
+            for (int r = 0; r < SA; r++) g[r] = gpre[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co) * N, tid);
+        }
 
         auto emit = [&](const double (&v_)[E], int j) {
 #pragma unroll
@@ -433,6 +448,12 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
             ntt_inv<BI, !DB>(acc, tw, data + (DB ? (it++ & 1) * BI * LDS_DATA : 0), tid);
+            if constexpr (STAGE == 0 && FK_EP_PREFETCH) {
+                if (j - BI < 0 && c + 1 < NCO) {   // last limb of this column: the next column's first operands arrive during its normalisation step
+#pragma unroll
+                    for (int r = 0; r < SA; r++) load_ops(gpre[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co + 1) * N, tid);
+                }
+            }
             if constexpr (FK_EARLY_FETCH == 0 && FK_SPREAD_FETCH_EP && BI == 1) {   // measured: 51.9 against 50.9 us per product (247 registers: over the cap, six spills): off
                 // the next limb's column_in 0 operands, one polynomial at a time between the parts of the normalisation step (see
                 // ks_trace_y: twelve loads per thread from all waves at once wait for the address unit)
