@@ -267,6 +267,9 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #ifndef FK_SPREAD_FETCH
 #define FK_SPREAD_FETCH 1      // ks_trace_y: the next limb's operand loads spread over the post-step (38.8 against 39.7 us per trace step)
 #endif
+#ifndef FK_LATE_BODY
+#define FK_LATE_BODY 1         // ks_trace_y: the body column of the input fetched and parked at the top of its own limb loop
+#endif
 #ifndef FK_EP_PREFETCH
 #define FK_EP_PREFETCH 0       // ep_run: the first output limb's operands of a column requested ahead of the column loop (75 spilled registers: off)
 #endif
@@ -1020,28 +1023,32 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
     const int sidx0 = (tid * ka.ginv) & (2 * N - 1);      // phi_g: destination i' = tid + T*k takes +-source i = i' * ginv mod 2N
     const int sstep = (T * ka.ginv) & (2 * N - 1);
 
-    double y0[E], y1[E];                      // Y of column 0 (body) / column 1 (mask) at the natural coefficients tid + T*k
-    if constexpr (IN_Y) {
-        const double* yp = reinterpret_cast<const double*>(ap);
+    // Y of the input at the natural coefficients tid + T*k.  Only the mask column (1) is needed in front of the forward
+    // transforms; the body column (0) is fetched and parked in LDS at the top of ITS limb loop (FK_LATE_BODY): eight loads,
+    // sixteen registers and a workgroup barrier fewer in the step's prologue
+    auto y_of = [](const RawX<KS_TRACE, SX>& r) {
+        double a_ = __builtin_fma(__builtin_fma((double)r.a[0], TWO_B, (double)r.a[1]), TWO_B, (double)r.a[2]);
+        a_ = r.neg ? -a_ : a_;                                       // the rotation's sign comes before the shift
+        return __builtin_floor(__builtin_fma(a_, 0.5, 0.5));        // ceil(A / 2)
+    };
+    auto load_column = [&](int col, double (&y)[E]) {
+        if constexpr (IN_Y) {
+            const double* yp = reinterpret_cast<const double*>(ap);
 #pragma unroll
-        for (int k = 0; k < E; k++) y1[k] = gload_f64(yp + N, (unsigned)(tid + T * k) * 8u);
+            for (int k = 0; k < E; k++) y[k] = gload_f64(yp + (long)col * N, (unsigned)(tid + T * k) * 8u);
+        } else {
+            RawX<KS_TRACE, SX> rw[E];
 #pragma unroll
-        for (int k = 0; k < E; k++) y0[k] = gload_f64(yp, (unsigned)(tid + T * k) * 8u);
-    } else {
-        RawX<KS_TRACE, SX> rm[E], rb[E];
+            for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, col, tid + T * k, rw[k]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, 1, tid + T * k, rm[k]);
-#pragma unroll
-        for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, 0, tid + T * k, rb[k]);
-        __builtin_amdgcn_sched_barrier(0);
-        auto y_of = [](const RawX<KS_TRACE, SX>& r) {
-            double a = __builtin_fma(__builtin_fma((double)r.a[0], TWO_B, (double)r.a[1]), TWO_B, (double)r.a[2]);
-            a = r.neg ? -a : a;                                        // the rotation's sign comes before the shift
-            return __builtin_floor(__builtin_fma(a, 0.5, 0.5));       // ceil(A / 2)
-        };
-#pragma unroll
-        for (int k = 0; k < E; k++) { y1[k] = y_of(rm[k]); y0[k] = y_of(rb[k]); }
-    }
+            for (int k = 0; k < E; k++) y[k] = y_of(rw[k]);
+        }
+    };
+    double y1[E];
+    load_column(1, y1);
+    [[maybe_unused]] double y0[E];
+    if constexpr (!FK_LATE_BODY) load_column(0, y0);
 #pragma unroll
     for (int k = 0; k < E; k++) ystage[tid + T * k] = y1[k];
     YSTAMP(1);
@@ -1071,27 +1078,18 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
     // so that only ONE column's Y is held in registers during the limb loops (the mask column goes first, from the registers
     // it already is in)
     YSTAMP(3);
-    lds_barrier();                     // slower waves may still be inside the wave-local exchanges of the forward transforms
+    if constexpr (!FK_LATE_BODY) {
+        lds_barrier();                 // slower waves may still be inside the wave-local exchanges of the forward transforms
 #pragma unroll
-    for (int k = 0; k < E; k++) bstage[tid + T * k] = y0[k];
-    // published by the barriers of the first inverse transform, which precede every gather
+        for (int k = 0; k < E; k++) bstage[tid + T * k] = y0[k];
+        // published by the barriers of the first inverse transform, which precede every gather
+    }
 
     YSTAMP(4);
     int it = 0;
 #pragma unroll 1
     for (int ci = 0; ci < 2; ci++) {
         const int co = 1 - ci;
-        double cq[E];                  // running quotient of this column's Y: the post-step takes its digits from the least significant one upwards, as the limbs are produced
-        if (co == 1) {
-#pragma unroll
-            for (int k = 0; k < E; k++) cq[k] = y1[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < E; k++) cq[k] = bstage[tid + T * k];   // this thread's own slots
-        }
-        double carry[E], od[E];
-#pragma unroll
-        for (int k = 0; k < E; k++) { carry[k] = 0.0; od[k] = 0.0; }
         OpRegs g[SX];
         auto fetch = [&](int j) {
 #pragma unroll
@@ -1099,6 +1097,25 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
         };
         fetch(SK - 1);   // (requested earlier the operand registers spill — in front of the forward transforms, or column 0's during
                          // column 1's last post-step: 45 us per step — or change nothing: behind the forward transforms)
+        double cq[E];                  // running quotient of this column's Y: the post-step takes its digits from the least significant one upwards, as the limbs are produced
+        if (co == 1) {
+#pragma unroll
+            for (int k = 0; k < E; k++) cq[k] = y1[k];
+        } else if constexpr (FK_LATE_BODY) {
+            // the body column of the input, fetched HERE (its round trip runs beside the operands' above) and parked in the third
+            // exchange buffer for the gathers of the body add: no transform of the limb loops touches that buffer, every wave
+            // is past the forward transforms (it has been through inverse transforms' barriers since), and the barriers of
+            // this column's first inverse transforms publish it before the first gather (limb 2)
+            load_column(0, cq);
+#pragma unroll
+            for (int k = 0; k < E; k++) bstage[tid + T * k] = cq[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; k++) cq[k] = bstage[tid + T * k];   // this thread's own slots
+        }
+        double carry[E], od[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) { carry[k] = 0.0; od[k] = 0.0; }
 #pragma unroll 1
         for (int j = SK - 1; j >= 0; j--) {
             double acc[1][E];
