@@ -267,6 +267,9 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #ifndef FK_SPREAD_FETCH
 #define FK_SPREAD_FETCH 1      // ks_trace_y: the next limb's operand loads spread over the post-step (38.8 against 39.7 us per trace step)
 #endif
+#ifndef FK_EARLY_FIRST
+#define FK_EARLY_FIRST 0       // ks_trace_y: column 1's first operands requested in front of the forward transforms (fits since FK_LATE_BODY; measured: 38.7-38.9 against 38.5-38.6 us per step: off)
+#endif
 #ifndef FK_LATE_BODY
 #define FK_LATE_BODY 1         // ks_trace_y: the body column of the input fetched and parked at the top of its own limb loop
 #endif
@@ -1071,6 +1074,13 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
             sidx = (sidx + sstep) & (2 * N - 1);
         }
     }
+    // the operands of column 1's first output limb: requested in front of the forward transforms (FK_EARLY_FIRST; the body
+    // column's registers are free there since FK_LATE_BODY), so that the column does not start with an exposed round trip
+    OpRegs g[SX];
+    if constexpr (FK_EARLY_FIRST) {
+#pragma unroll
+        for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + (SK - 1)) * 2 + 1) * N, tid);
+    }
     YSTAMP(2);
     fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before buffer 0 is overwritten
 
@@ -1090,12 +1100,11 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
 #pragma unroll 1
     for (int ci = 0; ci < 2; ci++) {
         const int co = 1 - ci;
-        OpRegs g[SX];
         auto fetch = [&](int j) {
 #pragma unroll
             for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
         };
-        fetch(SK - 1);   // (requested earlier the operand registers spill — in front of the forward transforms, or column 0's during
+        if (!FK_EARLY_FIRST || co == 0) fetch(SK - 1);   // (requested earlier the operand registers spill — in front of the forward transforms, or column 0's during
                          // column 1's last post-step: 45 us per step — or change nothing: behind the forward transforms)
         double cq[E];                  // running quotient of this column's Y: the post-step takes its digits from the least significant one upwards, as the limbs are produced
         if (co == 1) {
