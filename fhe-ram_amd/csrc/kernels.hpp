@@ -277,7 +277,7 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #define FK_EP_PREFETCH 0       // ep_run: the first output limb's operands of a column requested ahead of the column loop (75 spilled registers: off)
 #endif
 #ifndef FK_SPREAD_FETCH_EP
-#define FK_SPREAD_FETCH_EP 0   // the same in ep_run (247 registers: over the cap, six spills, 51.9 against 50.9 us per product: off)
+#define FK_SPREAD_FETCH_EP 1   // ep_run: the next limb's twelve operand loads in two bursts around the normalisation step (8 + 4: 50.7 against 51.3 us per product; interleaved with its parts: 247 registers, over the cap, six spilled, 51.9)
 #endif
 // Register cap of the chain kernels (see k_keyswitch_chain): one workgroup per CU, two waves per SIMD; above 240 registers the
 // two waves leave no room for the one-wave gate launch of read_prepare_write and the workgroup stays off that CU.
@@ -460,7 +460,7 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
                     for (int r = 0; r < SA; r++) load_ops(gpre[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co + 1) * N, tid);
                 }
             }
-            if constexpr (FK_EARLY_FETCH == 0 && FK_SPREAD_FETCH_EP && BI == 1) {   // measured: 51.9 against 50.9 us per product (247 registers: over the cap, six spills): off
+            if constexpr (FK_EARLY_FETCH == 0 && FK_SPREAD_FETCH_EP && BI == 1) {
                 // the next limb's column_in 0 operands, one polynomial at a time between the parts of the normalisation step (see
                 // ks_trace_y: twelve loads per thread from all waves at once wait for the address unit)
                 const bool more = j - BI >= 0;
@@ -469,14 +469,9 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
                 fetch1(0);
                 if (SA > 1) fetch1(1);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    if (SA > 2 && k == E / 2) { __builtin_amdgcn_sched_barrier(0); fetch1(2); __builtin_amdgcn_sched_barrier(0); }
-                    const double v = acc[0][k] + carry[k];
-                    const double cy = carry_of(v);
-                    carry[k] = cy;
-                    if (j < SA) gstore_i32(rp + glwe_off(j, co), (unsigned)(tid + T * k) * 4u, (int)digit_of(v, cy));
-                }
+                emit(acc[0], j);
+                __builtin_amdgcn_sched_barrier(0);
+                if (SA > 2) fetch1(2);
                 static_assert(SA <= 3, "three operand polynomials per half");
             } else {
                 if constexpr (FK_EARLY_FETCH == 0) { if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid); }   // overlaps the normalisation step
