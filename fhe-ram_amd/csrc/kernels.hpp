@@ -267,6 +267,9 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #ifndef FK_SPREAD_FETCH
 #define FK_SPREAD_FETCH 1      // ks_trace_y: the next limb's operand loads spread over the post-step (38.8 against 39.7 us per trace step)
 #endif
+#ifndef FK_WARM_OPERANDS
+#define FK_WARM_OPERANDS 0     // ep_run: the first output limb's operands touched in front of the forward transforms (every line: 52.1 against 51.3 us per product; one stripe per polynomial: neutral): off
+#endif
 #ifndef FK_EARLY_FIRST
 #define FK_EARLY_FIRST 0       // ks_trace_y: column 1's first operands requested in front of the forward transforms (fits since FK_LATE_BODY; measured: 38.7-38.9 against 38.5-38.6 us per step: off)
 #endif
@@ -335,7 +338,9 @@ __device__ __forceinline__ long big_ct() { return ((long)blockIdx.y * gridDim.x 
 // (k_ext_product_chain): load_tw = false skips the twiddle table (already in LDS from the previous step).
 template <int SA, int SG, int NCO, int STAGE = 0>
 __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
-                                       const double* __restrict__ tw_g, double* __restrict__ big, double* lds, bool load_tw, const int tid) {
+                                       const double* __restrict__ tw_g, double* __restrict__ big, double* lds, bool load_tw, const int tid,
+                                       const bool stamp_on = false) {
+    YSTAMP(0);
     if constexpr (STAGE == 2) {
         const int co = (int)blockIdx.z;
         int32_t* rp = at(res);
@@ -365,6 +370,16 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
 
     double x0[SA][E], x1[SA][E];   // limbs of column 0 / column 1 of a
     OpRegs gpre[SA];               // operands requested ahead of the column loop (FK_EP_PREFETCH)
+    // The operands of a product are touched for the first time by every workgroup at once, when the first output limb of the
+    // first column asks for them: the stamps (tools/stamp_chain.py) show 3 us more for that limb than for any other (cold
+    // lines, cold translations).  The registers to request them earlier are not there (FK_EP_PREFETCH spills), but ONE 8-byte
+    // load per thread and operand polynomial, 64 bytes apart, touches every line of the six polynomials of that limb: issued
+    // here, in front of the forward transforms, summed into one register that nothing reads.
+    [[maybe_unused]] double warm = 0.0;
+    if constexpr (STAGE == 0 && FK_WARM_OPERANDS) {
+#pragma unroll
+        for (int w = 0; w < 2 * SA; w++) warm += ggsw[(long)((w * SG + (SG - 1)) * 2 + co0) * N + tid];   // (one coalesced 4 KB stripe per polynomial: translations and the first lines)
+    }
     {
         int xi[SA][E];
 #pragma unroll
@@ -380,7 +395,9 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
         for (int r = 0; r < SA; r++)
 #pragma unroll
             for (int k = 0; k < E; k++) xi[r][k] = gload_i32(ap + glwe_off(r, 1), (unsigned)(tid + T * k) * 4u);
+        YSTAMP(1);
         fwd_all<SA>(x0, tw, data, tid);
+        YSTAMP(2);
 #pragma unroll
         for (int r = 0; r < SA; r++)
 #pragma unroll
@@ -392,7 +409,9 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
             for (int r = 0; r < SA; r++) load_ops(gpre[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co0) * N, tid);
         }
         fwd_all<SA>(x1, tw, data, tid);
+        YSTAMP(3);
     }
+    if constexpr (STAGE == 0 && FK_WARM_OPERANDS) asm volatile("" ::"v"(warm));   // the loads are kept; their values end here
     if constexpr (STAGE == 1) {
         const int co = (int)blockIdx.z / SG, j = SG - 1 - (int)blockIdx.z % SG;
         OpRegs g[SA];
@@ -449,11 +468,13 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
                 if (b > 0) ep_fetch0<SA, SG>(g, ggsw, j - b, co, tid);
                 ep_mac<SA, SG>(acc[b], x0, x1, g, ggsw, j - b, co, j - b - 1, tid);
             }
+            YSTAMP(8 + (c * SG + (SG - 1 - j)) * 4);
             if constexpr (FK_EARLY_FETCH == 1) {
                 if (j - BI >= 0) ep_fetch0<SA, SG>(g, ggsw, j - BI, co, tid);
                 __builtin_amdgcn_sched_barrier(0);
             }
             ntt_inv<BI, !DB>(acc, tw, data + (DB ? (it++ & 1) * BI * LDS_DATA : 0), tid);
+            YSTAMP(9 + (c * SG + (SG - 1 - j)) * 4);
             if constexpr (STAGE == 0 && FK_EP_PREFETCH) {
                 if (j - BI < 0 && c + 1 < NCO) {   // last limb of this column: the next column's first operands arrive during its normalisation step
 #pragma unroll
@@ -478,6 +499,7 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
 #pragma unroll
                 for (int b = 0; b < BI; b++) emit(acc[b], j - b);
             }
+            YSTAMP(10 + (c * SG + (SG - 1 - j)) * 4);
         }
         if constexpr (REM == 1) {
             double acc[1][E];
@@ -488,6 +510,7 @@ __device__ __forceinline__ void ep_run(GlweRef a, GlweRef res, const double* __r
             emit(acc[0], 0);
         }
     }
+    YSTAMP(5);
 }
 
 template <int SA, int SG, int NCO, int STAGE = 0>
@@ -530,7 +553,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         asm volatile("" : "+v"(tid));   // per-step copy the optimiser cannot see through: keeps it from hoisting every
                                         // thread-index-derived address out of the step loop (56 spilled registers)
         __builtin_assume(tid >= 0 && tid < T);   // ... but it may still use the range (index patterns fold to immediates)
-        ep_run<SA, SG, 2, 0>(in, out, ca.ggsw[i], ca.tw, nullptr, lds, i == 0, tid);
+        ep_run<SA, SG, 2, 0>(in, out, ca.ggsw[i], ca.tw, nullptr, lds, i == 0, tid, YSTAMP_STEP(i + 1));
         __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
         in = out;
     }

@@ -27,3 +27,21 @@ for rep in range(3):
             prev = s[4] if (ci == 0 and q == 0) else s[b - 1]
             print(f"  column {1-ci} limb {3-q}: (operand wait +) MAC {(s[b]-prev)*tick:6.0f}  inverse transform {(s[b+1]-s[b])*tick:6.0f}  fetch + body add {(s[b+2]-s[b+1])*tick:6.0f}  emit {(s[b+3]-s[b+2])*tick:6.0f}   (at {(s[b+3]-t0)*tick:8.0f})")
     print(f"  step done                                     {(s[5]-t0)*tick:8.0f}")
+
+# the same for an inner product of the product chain (kind 1): stamps 0..3 prologue, then per (column, limb): MAC, inverse, post-step
+for rep in range(2):
+    ram.bench_chain(1, 256, 4, 5)
+    st = (C.c_uint64 * 192)()
+    L.fheram_debug_stamps(ram._h, st, 192)
+    s = np.array([int(x) for x in st], dtype=np.int64)
+    t0 = s[0]
+    print(f"== rep {rep}: third product of k_ext_product_chain<3,4>, batch 256, wave 0 of workgroup 0; shader-clock ticks since the step began")
+    print(f"  column 0 loaded, converted                    {s[1]-t0:8d}")
+    print(f"  three forward transforms (column 0)           {s[2]-t0:8d}")
+    print(f"  three forward transforms (column 1)           {s[3]-t0:8d}")
+    for c in range(2):
+        for q in range(4):
+            b = 8 + (c * 4 + q) * 4
+            prev = s[3] if (c == 0 and q == 0) else s[b - 2]
+            print(f"  column {c} limb {3-q}: (operand waits +) 6 MACs {s[b]-prev:6d}  inverse transform {s[b+1]-s[b]:6d}  fetch + normalisation step {s[b+2]-s[b+1]:6d}   (at {s[b+2]-t0:8d})")
+    print(f"  step done                                     {s[5]-t0:8d}")
