@@ -977,6 +977,23 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
                 __builtin_amdgcn_sched_barrier(0);
             }
             ntt_inv<KBI, !DB, (SX > 3)>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);   // <= 3 MAC terms: no initial reduce
+            if constexpr (FK_EARLY_FETCH == 0 && FK_SPREAD_FETCH && KBI == 1 && SX == 3) {
+                // next limb's operands: their latency overlaps the post-step; one operand polynomial at a time around its parts (see
+                // ks_trace_y: twelve loads per thread from all waves at once queue at the address unit)
+                const bool more = j - KBI >= 0;
+                auto fetch1 = [&](int r) { if (more) load_ops(g[r], ka.key + (long)((r * SK + (j - KBI)) * 2 + co) * N, tid); };
+                fetch1(0);
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(10 + 4 * (SK - 1 - j) + 24 * c);
+                add_body(acc[0], j);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch1(1);
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(11 + 4 * (SK - 1 - j) + 24 * c);
+                emit(acc[0], j);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch1(2);
+            } else {
             if constexpr (FK_EARLY_FETCH == 0) { if (j - KBI >= 0) fetch(j - KBI); }   // (FK_EARLY_FETCH == 2: timing diagnostic, operands never refetched, results wrong)   // next limb's operands: their latency overlaps the post-step
             STAMP(10 + 4 * (SK - 1 - j) + 24 * c);
 #pragma unroll
@@ -984,6 +1001,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
             STAMP(11 + 4 * (SK - 1 - j) + 24 * c);
 #pragma unroll
             for (int b = 0; b < KBI; b++) emit(acc[b], j - b);
+            }
         }
         STAMP(5 + 24 * c);
         if constexpr (REM == 1) {
