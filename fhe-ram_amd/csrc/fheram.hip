@@ -122,7 +122,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* cy = getenv("FHERAM_CHAIN_Y");
-        c->chain_y = (cy && cy[0] == '0') ? 0 : 1;
+        c->chain_y = cy ? (cy[0] == '0' ? 0 : (cy[0] == '1' ? 1 : 2)) : 2;
         const char* gr = getenv("FHERAM_GRAPH");
         c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
         // a captured launch sequence must be a pure function of (context, address, op): under replay the write always
@@ -142,8 +142,10 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product_fine<4, 5>));
     LDSATTR((&k_ext_product_chain<3, 4>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
-    LDSATTR((&k_keyswitch_chain<3, 4, 3, true>));
-    LDSATTR((&k_keyswitch_chain<3, 5, 3, true>));
+    LDSATTR((&k_keyswitch_chain<3, 4, 3, 1>));
+    LDSATTR((&k_keyswitch_chain<3, 4, 3, 2>));
+    LDSATTR((&k_keyswitch_chain<3, 5, 3, 2>));
+    LDSATTR((&k_keyswitch_chain<3, 5, 3, 1>));
     LDSATTR((&k_trace_tail<3, 4, 3>));
     LDSATTR((&k_chain_mid<false, 4, 3, 2>)); LDSATTR((&k_chain_mid<false, 5, 3, 2>)); LDSATTR((&k_chain_mid<true, 4, 3, 2>));
     LDSATTR((&k_chain_mid<false, 4, 1, 1>)); LDSATTR((&k_chain_mid<false, 5, 1, 1>));

@@ -1225,6 +1225,250 @@ __device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool l
     YSTAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------
+// ks_trace_z (round 4): the same trace step with the normalisation in CLOSED FORM — one accumulator per coefficient and
+// column instead of a carry chain over the limbs.
+//
+// vec_znx_big_normalize of the SK un-normalised limbs v_j = acc_j + x_j (x_j: limb j of rsh1(a), zero for j >= 3) walks
+// them from the least significant one, carry = floor(v/2^17 + 1/2), and drops the carry out of limb 0.  With balanced
+// digits that is: the extra limbs j >= 3 only contribute their rounded carry  e = carry(v_3 + carry(v_4 ...)),  and the
+// three output digits are THE balanced base-2^17 digits of
+//        V = v_0 * 2^34 + v_1 * 2^17 + v_2 + e        taken modulo 2^51
+// (digits in [-2^16, 2^16): the window [-C, 2^51 - C), C = 2^16 + 2^33 + 2^50).  Modulo 2^51 only v_1 mod 2^34 and
+// v_0 mod 2^17 matter, and sum_j x_j * 2^(17 (2 - j)) is Y itself (its top "digit" is the unwrapped quotient), so
+//        V = Y  [+- Y_body(src) for the body column: vec_znx_big_add_small of phi_g(rsh1(a).body)]
+//            + e + acc_2 + cmod(acc_1, 2^34) * 2^17 + cmod(acc_0, 2^17) * 2^34          (cmod: centred remainder)
+// with every term an exact integer below 2^50 in magnitude (|acc_j| < 2^47, |Y| < 2^50 + 2^33): |V| < 2^52.2, exact in
+// FP64.  The output is A = V - 2^51 * floor((V + C) / 2^51), handed over as Y' = ceil(A / 2) as in ks_trace_y.
+// Same integers as the limb-by-limb walk (tests: every digest and oracle comparison of the Y form also runs in this form).
+//
+// What it buys: (i) the post-step of an output limb is 1-4 FP64 instructions per coefficient instead of ~9 (+ ~8 for the
+// body column's three digit gathers: the body is gathered ONCE, as Y); (ii) no carry, no running quotient of Y: 32 registers
+// fewer, which pay for (iii) the operands of the next output limbs requested BEFORE the inverse transforms (their fetch —
+// 96 KB per limb through the CU's 64 B/clk address unit, 1 500 cycles — runs under the transforms instead of in front of
+// the MAC) and (iv) TWO inverse transforms at a time (limbs are independent now: no carry chain orders them), which share
+// barriers and LDS round trips as the three forward transforms always did.
+// ---------------------------------------------------------------------------------------
+constexpr double TWO_51 = 2251799813685248.0;          // 2^51
+constexpr double INV_TWO_51 = 1.0 / 2251799813685248.0;
+constexpr double INV_TWO_2B = 1.0 / 17179869184.0;      // 2^-34
+constexpr double WIN_C = 65536.0 + 8589934592.0 + 1125899906842624.0;   // 2^16 + 2^33 + 2^50
+// centred remainder of x modulo 2^17 / 2^34 (x an exact integer)
+__device__ __forceinline__ double cmod17(double x) { return __builtin_fma(-__builtin_floor(__builtin_fma(x, INV_TWO_B, 0.5)), TWO_B, x); }
+__device__ __forceinline__ double cmod34(double x) { return __builtin_fma(-__builtin_floor(__builtin_fma(x, INV_TWO_2B, 0.5)), TWO_2B, x); }
+// V -> the integer whose balanced base-2^17 digits are the three output limbs (top carry dropped)
+__device__ __forceinline__ double window51(double v) { return __builtin_fma(-__builtin_floor(__builtin_fma(v, INV_TWO_51, WIN_C * INV_TWO_51)), TWO_51, v); }
+// adds output limb j's contribution to V (SO = 3 output limbs; limbs j >= 3 go through the extra-carry e first)
+template <int SK>
+__device__ __forceinline__ void fold_limb(double (&od)[E], double (&ec)[E], const double (&acc)[E], int j) {
+    // (j is wave uniform: one scalar branch per limb, not per coefficient)
+    if (j >= 3) {
+        if (SK >= 5 && j < SK - 1) {
+#pragma unroll
+            for (int k = 0; k < E; k++) ec[k] = carry_of(acc[k] + ec[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; k++) ec[k] = carry_of(acc[k]);
+        }
+        if (j == 3) {
+#pragma unroll
+            for (int k = 0; k < E; k++) od[k] += ec[k];
+        }
+    } else if (j == 2) {
+#pragma unroll
+        for (int k = 0; k < E; k++) od[k] += acc[k];
+    } else if (j == 1) {
+#pragma unroll
+        for (int k = 0; k < E; k++) od[k] = __builtin_fma(cmod34(acc[k]), TWO_B, od[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; k++) od[k] = __builtin_fma(cmod17(acc[k]), TWO_2B, od[k]);
+    }
+}
+#ifndef FK_Z_BI
+#define FK_Z_BI 2          // inverse transforms per batch in ks_trace_z
+#endif
+#ifndef FK_Z_PREFETCH
+#define FK_Z_PREFETCH 0    // ks_trace_z: operand polynomials (0..3) of the next limbs requested before the inverse transforms (the others behind them)
+#endif
+#ifndef FK_Z_SKEW
+#define FK_Z_SKEW 1          // ks_trace_z: the two inverse transforms of a batch half a phase apart (ntt_inv2_skew)
+#endif
+#ifndef FK_Z_UNROLL_COLS
+#define FK_Z_UNROLL_COLS 1
+#endif
+#ifndef FK_Z_PARK
+#define FK_Z_PARK 1        // ks_trace_z: the body column's V parked in LDS while the mask column is produced
+#endif
+template <int SK, bool IN_Y, bool OUT_Y>
+__device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool load_tw, const int tid, const bool stamp_on = false) {
+    YSTAMP(0);
+    constexpr int SX = 3;
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    TwRegs twr;
+    if (load_tw) twiddles_issue(twr, ka.tw, tid);
+    const int32_t* ap = at(ka.a);
+    int32_t* op = at(ka.out);
+    double* ystage = data;                 // exchange buffer 0: Y of the mask column, natural order
+    double* bstage = data + LDS_DATA;      // exchange buffer 1: Y of the body column (both are free until the forward transforms)
+    const int sidx0 = (tid * ka.ginv) & (2 * N - 1);      // phi_g: destination i' = tid + T*k takes +-source i = i' * ginv mod 2N
+    const int sstep = (T * ka.ginv) & (2 * N - 1);
+
+    auto y_of = [](const RawX<KS_TRACE, SX>& r) {
+        double a_ = __builtin_fma(__builtin_fma((double)r.a[0], TWO_B, (double)r.a[1]), TWO_B, (double)r.a[2]);
+        a_ = r.neg ? -a_ : a_;                                       // the rotation's sign comes before the shift
+        return __builtin_floor(__builtin_fma(a_, 0.5, 0.5));        // ceil(A / 2)
+    };
+    auto load_column = [&](int col, double (&y)[E]) {
+        if constexpr (IN_Y) {
+            const double* yp = reinterpret_cast<const double*>(ap);
+#pragma unroll
+            for (int k = 0; k < E; k++) y[k] = gload_f64(yp + (long)col * N, (unsigned)(tid + T * k) * 8u);
+        } else {
+            RawX<KS_TRACE, SX> rw[E];
+#pragma unroll
+            for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, col, tid + T * k, rw[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < E; k++) y[k] = y_of(rw[k]);
+        }
+    };
+    // V of both columns starts as the column's own Y (natural order); both are staged for the gathers through phi_g
+    double v1[E], v0[E];
+    load_column(1, v1);
+    load_column(0, v0);
+#pragma unroll
+    for (int k = 0; k < E; k++) { ystage[tid + T * k] = v1[k]; bstage[tid + T * k] = v0[k]; }
+    YSTAMP(1);
+    if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();   // its barrier also publishes the staged columns
+
+    // the digits of the mask column seen through phi_g (to be transformed), and phi_g(body) added to the body column's V
+    double xh[SX][E];
+    {
+        int sidx = sidx0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const bool ng = sidx >= N;
+            double c = ystage[sidx & (N - 1)];
+            const double b = bstage[sidx & (N - 1)];
+            const double d2 = take_digit(c);
+            const double d1 = take_digit(c);
+            xh[2][k] = ng ? -d2 : d2;
+            xh[1][k] = ng ? -d1 : d1;
+            xh[0][k] = ng ? -c : c;
+            v0[k] += ng ? -b : b;
+            sidx = (sidx + sstep) & (2 * N - 1);
+        }
+    }
+    // operands of the first output limb of column 1: in flight during the forward transforms
+    OpRegs g[SX];
+    auto fetch = [&](int j, int co, int r0, int r1) {
+#pragma unroll
+        for (int r = 0; r < SX; r++)
+            if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
+    };
+    constexpr int PF = FK_Z_PREFETCH;   // operand polynomials of the next limb requested BEFORE the transforms (the others behind them)
+    fetch(SK - 1, 1, 0, PF);
+    YSTAMP(2);
+    fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
+    YSTAMP(3);
+    // the body column's V waits in the third exchange buffer, in this WAVE's own region of it (the inverse transforms use
+    // buffers 0 and 1; this wave is through the forward transforms, whose wave-local exchanges are the only other accesses
+    // to that region, and the cross-wave reads of their first exchange were fenced by a barrier inside it)
+    double* park = data + 2 * LDS_DATA + (tid >> 6) * (64 * (E + 1)) + (tid & 63);
+    if constexpr (FK_Z_PARK) {
+#pragma unroll
+        for (int k = 0; k < E; k++) park[64 * k] = v0[k];
+    }
+
+#if FK_Z_UNROLL_COLS
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+    for (int ci = 0; ci < 2; ci++) {
+        const int co = 1 - ci;
+        double od[E], ec[E];
+        if constexpr (FK_Z_PARK) {
+            if (co == 1) {
+#pragma unroll
+                for (int k = 0; k < E; k++) od[k] = v1[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < E; k++) od[k] = park[64 * k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; k++) od[k] = (co == 1) ? v1[k] : v0[k];
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) ec[k] = 0.0;
+        fetch(SK - 1, co, PF, SX);   // (the first PF polynomials were requested in front of the forward transforms / of column 1's last transforms)
+#pragma unroll 1
+        for (int j = SK - 1; j >= 0; j -= FK_Z_BI) {
+            const bool two = FK_Z_BI == 2 && j >= 1;
+            double acc[FK_Z_BI][E];
+#pragma unroll
+            for (int b = 0; b < FK_Z_BI; b++)
+#pragma unroll
+                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
+            // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
+#pragma unroll
+            for (int r = 0; r < SX; r++) {
+                mac_regs(acc[0], xh[r], g[r]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (two) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (FK_Z_BI == 2) {
+                if (two) {
+#pragma unroll
+                    for (int r = 0; r < SX; r++) mac_regs(acc[FK_Z_BI - 1], xh[r], g[r]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next limbs' first operands (or the next column's): requested HERE, their fetch runs under the transforms
+            if constexpr (PF > 0) {
+                if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, 0, PF);
+                else if (ci == 0) fetch(SK - 1, 0, 0, PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
+            if (two) {
+                if constexpr (FK_Z_SKEW && FK_Z_BI == 2) ntt_inv2_skew<true, false>(*reinterpret_cast<double(*)[2][E]>(&acc[0]), tw, data, data + LDS_DATA, tid);
+                else ntt_inv<FK_Z_BI, true, false>(acc, tw, data, tid);
+                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+                fold_limb<SK>(od, ec, acc[0], j);
+                fold_limb<SK>(od, ec, acc[FK_Z_BI - 1], j - 1);
+            } else {
+                ntt_inv<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
+                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+                fold_limb<SK>(od, ec, acc[0], j);
+            }
+            if constexpr (PF < SX) {   // the rest of the next limb's operands: their fetch runs under the fold and the first products
+                if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, PF, SX);
+            }
+            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            double a_ = window51(od[k]);
+            if constexpr (OUT_Y) {
+                double* yo = reinterpret_cast<double*>(op) + (long)co * N;
+                gstore_f64(yo, (unsigned)(tid + T * k) * 8u, __builtin_floor(__builtin_fma(a_, 0.5, 0.5)));
+            } else {
+                const double d2 = take_digit(a_);
+                const double d1 = take_digit(a_);
+                gstore_i32(op + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
+                gstore_i32(op + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
+                gstore_i32(op + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
+            }
+        }
+    }
+    YSTAMP(5);
+}
+
 // GLWE::trace(start, start + n) (ram.rs:457,540,572,616,621 and the packer levels in which every
 // leaf is alone) as ONE launch: n trace steps on the same ciphertext, one workgroup per ciphertext, ping-pong
 // between the workgroup's own slots of two buffers (see k_ext_product_chain).  Only the first step may read its
@@ -1251,7 +1495,7 @@ struct KsChainArgs {
 // file, and ANY other wave resident on the CU — the one-wave gate launch that read_prepare_write parks on the side stream is
 // enough — keeps the workgroup off that CU: a 256-workgroup launch on 256 CUs then runs in two rounds (+0.24 ms per
 // read_prepare_write, measured when the Y-form kernel first compiled to 250).  Capped so that a small wave still fits.
-template <int SX, int SK, int SO, bool YF = false>
+template <int SX, int SK, int SO, int YF = 0>   // YF: 0 limbs, 1 Y form (ks_trace_y), 2 Y form with the closed-form normalisation (ks_trace_z)
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.pred) {
@@ -1278,7 +1522,12 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
         __builtin_assume(tid >= 0 && tid < T);
-        if constexpr (YF) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y); n >= 2
+        if constexpr (YF == 2) {
+            static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
+            if (i == 0) ks_trace_z<SK, false, true>(ka, lds, true, tid);
+            else if (i + 1 < ca.n) ks_trace_z<SK, true, true>(ka, lds, false, tid, YSTAMP_STEP(i));
+            else ks_trace_z<SK, true, false>(ka, lds, false, tid);
+        } else if constexpr (YF == 1) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y); n >= 2
             static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
             if (i == 0) ks_trace_y<SK, false, true>(ka, lds, true, tid);
             else if (i + 1 < ca.n) ks_trace_y<SK, true, true>(ka, lds, false, tid, YSTAMP_STEP(i));

@@ -320,10 +320,16 @@ __device__ __forceinline__ void fwd_rec(double (&x)[B][E], const TwPass& t, cons
         fwd_rec<Q + 1, B>(x, tn, tw, data, tid);
     }
 }
+#ifndef FK_INV_SERIAL
+#define FK_INV_SERIAL 1   // batched inverse transforms: the polynomials' passes one after the other (no interleaving by the scheduler: the butterflies' temporaries are shared instead of doubled); the batch still shares exchanges and barriers
+#endif
 template <int Q, int B>
 __device__ __forceinline__ void inv_rec(double (&x)[B][E], const TwPass& t, const double* tw, double* data, int tid) {
 #pragma unroll
-    for (int b = 0; b < B; b++) inv_pass<Q>(x[b], t);
+    for (int b = 0; b < B; b++) {
+        inv_pass<Q>(x[b], t);
+        if constexpr (B > 1 && FK_INV_SERIAL) __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (Q > 0) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
@@ -375,6 +381,64 @@ __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, dou
     inv_rec<NPASS - 1, B>(x, t, tw, data, tid);
 #pragma unroll
     for (int b = 0; b < B; b++)
+#pragma unroll
+        for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+}
+
+// ---- two inverse transforms, software pipelined against each other (round 4) ------------------------------------
+// ntt_inv<2> runs the two polynomials in step: both passes, then both exchanges (all writes, then all reads), so a wave's
+// LDS traffic and its butterflies alternate and the LDS round trips are exposed.  Here polynomial B runs HALF A PHASE
+// behind A: the exchange of one (its writes and, right behind them, its reads: a wave's DS operations execute in order,
+// and the wave-local exchanges 2 and 1 touch only the wave's own region) is in flight while the wave computes the other's
+// pass.  Same operations per polynomial, same values; exchange 0 crosses waves and keeps its barrier.
+template <int X>
+__device__ __forceinline__ void xw_inv(const double (&x)[E], double* data, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) data[lay<X>(pat<X + 1>(tid, k))] = x[k];
+}
+template <int X>
+__device__ __forceinline__ void xr_inv(double (&x)[E], const double* data, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = data[lay<X>(pat<X>(tid, k))];
+}
+__device__ __forceinline__ void reduce01(double (&x)[E]) { x[0] = reduce(x[0]); x[1] = reduce(x[1]); }
+// FENCE / PRE as ntt_inv.  d0 / d1: the exchange buffers of the two polynomials.
+template <bool FENCE = true, bool PRE = true>
+__device__ __forceinline__ void ntt_inv2_skew(double (&x)[2][E], const double* tw, double* d0, double* d1, int tid) {
+    static_assert(LOGE == 3 && NPASS == 4, "written for the radix-8 transform");
+    if constexpr (PRE) {
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
+    }
+    TwPass t3, t2, t1, t0;
+    inv_twiddles<3>(t3, tw, tid);
+    if constexpr (FENCE) lds_barrier();
+    inv_pass<3>(x[0], t3); reduce01(x[0]);
+    xw_inv<2>(x[0], d0, tid); wave_lds_fence(); xr_inv<2>(x[0], d0, tid);
+    inv_twiddles<2>(t2, tw, tid);
+    inv_pass<3>(x[1], t3); reduce01(x[1]);
+    xw_inv<2>(x[1], d1, tid); wave_lds_fence(); xr_inv<2>(x[1], d1, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    inv_pass<2>(x[0], t2); reduce01(x[0]);
+    xw_inv<1>(x[0], d0, tid); wave_lds_fence(); xr_inv<1>(x[0], d0, tid);
+    inv_twiddles<1>(t1, tw, tid);
+    inv_pass<2>(x[1], t2); reduce01(x[1]);
+    xw_inv<1>(x[1], d1, tid); wave_lds_fence(); xr_inv<1>(x[1], d1, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    inv_pass<1>(x[0], t1); reduce01(x[0]);
+    xw_inv<0>(x[0], d0, tid);
+    inv_twiddles<0>(t0, tw, tid);
+    inv_pass<1>(x[1], t1); reduce01(x[1]);
+    xw_inv<0>(x[1], d1, tid);
+    lds_barrier();
+    xr_inv<0>(x[0], d0, tid);
+    xr_inv<0>(x[1], d1, tid);
+    inv_pass<0>(x[0], t0);
+    inv_pass<0>(x[1], t0);
+#pragma unroll
+    for (int b = 0; b < 2; b++)
 #pragma unroll
         for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
 }
