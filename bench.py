@@ -90,32 +90,65 @@ def pmc_traffic_per_launch():
     return json.load(open(path)).get("dominant_kernel", {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(max_addr, ws, seed, threads, crypto=None):
-    """Times the oracle (CPU restatement, kind 'port') on the same workload: one read + one
-    read_prepare_write + one write.  threads == 1: ONE of the WORDSIZE sub-RAMs (the reference processes them
-    one after the other, ram.rs:187-190; scaled by the caller).  threads > 1: the whole RAM with the oracle's
-    OpenMP variant (sub-RAMs and the rows of the per-row loops in parallel)."""
+def make_inputs(p, ws, s_evk, n_digits, rows_local, seed_keys=1234, seed_rows=4321):
+    """The synthetic inputs of a run: evaluation keys, address digits, RAM rows, the words of the write.  ONE function for the
+    GPU legs and the oracle leg (identical inputs, examples/fhe-ram.rs:98-115 checks the result it has just timed)."""
+    rng = np.random.default_rng(seed_keys)
+    inp = {"atk": synth(rng, (12, 3 * s_evk * 2 * N)), "atk_inv": synth(rng, 4 * 5 * 2 * N), "tsk": synth(rng, 4 * 5 * 2 * N),
+           "addr": synth(rng, (n_digits, p.ggsw_len()))}
+    rng = np.random.default_rng(seed_rows)
+    inp["rows"] = synth(rng, (ws, rows_local, p.glwe_len()))
+    inp["words"] = synth(rng, (ws, p.glwe_len()))
+    return inp
+
+
+def oracle_native():
+    """the CPU leg is built for the host it runs on.  liboracle.so is built portable (-march=x86-64-v2: it
+    travels from the build container to the GPU box); this builds the same sources -march=native on THIS machine and
+    makes pyoracle load that.  Returns the flags in use."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import subprocess
+    if os.environ.get("FO_LIB"):
+        return "FO_LIB=" + os.environ["FO_LIB"]
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "_native/liboracle_native.so"], check=True, timeout=300,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.environ["FO_LIB"] = os.path.join(ROOT, "oracle", "_native", "liboracle_native.so")
+        return "-O3 -march=native (built on this host)"
+    except Exception as e:   # no compiler on the box: the portable build
+        return f"-O3 -march=x86-64-v2 (native build failed: {type(e).__name__})"
+
+
+def cpu_baseline(max_addr, ws, inp, threads, crypto=None, sub_ram=None):
+    """Times the oracle (CPU restatement, kind 'port') on the SAME inputs as the GPU legs: one read + one
+    read_prepare_write + one write.  threads == 1: sequential, as the reference (ram.rs:187-190); sub_ram = i: only
+    sub-RAM i (beyond 2^18; scaled by the caller).  threads > 1: the oracle's OpenMP variant (sub-RAMs and the rows of
+    the per-row loops in parallel).  Returns the three times and the three outputs (result of read, of
+    read_prepare_write, rows after write)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    o = po.Oracle(po.OParams(max_addr=max_addr, word_size=ws, **(crypto or {}))).set_threads(threads)
-    p = o.p
-    rng = np.random.default_rng(seed)
+    o = po.Oracle(po.OParams(max_addr=max_addr, word_size=ws if sub_ram is None else 1, **(crypto or {}))).set_threads(threads)
     evk = {"gal_els": np.array([int(po.lib().fo_galois_element(12, i)) for i in range(12)], dtype=np.int64),
-           "atk_glwe": synth(rng, (12, p.atk_trace_len)), "atk_ggsw_inv": synth(rng, p.evk_inv_len),
-           "tsk": synth(rng, p.evk_inv_len)}
+           "atk_glwe": inp["atk"], "atk_ggsw_inv": inp["atk_inv"], "tsk": inp["tsk"]}
     keys = o.keys_prepare(evk)
-    addr = o.address_new(synth(rng, (o.n_digits, p.ggsw_len)))
+    addr = o.address_new(inp["addr"])
     ram = o.ram_new()
-    ram.load(synth(rng, (ws, p.rows, p.glwe_len)))
-    w = synth(rng, (ws, p.glwe_len))
+    sel = slice(None) if sub_ram is None else slice(sub_ram, sub_ram + 1)
+    ram.load(np.ascontiguousarray(inp["rows"][sel]))
+    w = np.ascontiguousarray(inp["words"][sel])
     t0 = time.perf_counter()
-    ram.read(addr, keys)
+    r = ram.read(addr, keys)
     t1 = time.perf_counter()
-    ram.read_prepare_write(addr, keys)
+    q = ram.read_prepare_write(addr, keys)
     t2 = time.perf_counter()
     ram.write(w, addr, keys)
     t3 = time.perf_counter()
-    return t1 - t0, t2 - t1, t3 - t2
+    return (t1 - t0, t2 - t1, t3 - t2), {"read": r, "rpw": q, "rows_after_write": ram.store()}
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int64).tobytes()).hexdigest()
 
 
 def host_cpu():
@@ -247,16 +280,19 @@ def bench_group(args):
     log_entries = int(np.log2(max_addr))
     print(json.dumps({
         "metric": f"encrypted RAM read ops/s + write ops/s at 2^{args.log_max_addr} entries; achieved HBM GB/s vs peak",
-        "value": 2 * args.steps / elapsed * weight,
+        "value": 2 * args.steps / elapsed,
         "unit": "RAM ops/s (1 read + 1 write[=rpw+write] per step)" + (
-            f"; an op on the {n}*2^{args.log_max_addr}-entry sharded RAM counts as {n} ops of the 2^{args.log_max_addr}-entry metric" if weight > 1 else ""),
+            f" of the ONE 2^{log_entries}-entry RAM sharded over the {n} GPUs (weak scaling: 2^{args.log_max_addr} entries per GPU; "
+            f"value(N) / value(1) = T(1) / T(N) is the weak-scaling efficiency)" if weight > 1 else ""),
         "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "mode": "group", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"Ram::read + Ram::read_prepare_write + Ram::write, MAX_ADDR=2^{log_entries}, WORDSIZE={ws}, N=4096, base2k=17, rank=1"
                                " (BASELINE.json configs[2]+[3]; configs[4] sharding)",
                    "parallelism": f"1 process, {n} GPUs: 1 RAM of 2^{log_entries} entries, rows r = g (mod {n}) on GPU g, one host thread per GPU; "
                                   "peer-to-peer copies: partial packs to the root per read, ct_lo to every shard per write (fheram_group_*)"},
-        "ram_ops_s_raw": 2 * args.steps / elapsed, "read_ms": read_ms, "read_prepare_write_ms": rpw_ms, "write_ms": write_ms,
+        "ram_ops_s_raw": 2 * args.steps / elapsed,
+        "ops_weighted_by_ram_size": None if weight == 1 else 2 * args.steps / elapsed * weight,
+        "read_ms": read_ms, "read_prepare_write_ms": rpw_ms, "write_ms": write_ms,
         "timing": "host wall clock per synchronous group call"}))
 
 
@@ -345,14 +381,13 @@ def main():
     else:
         ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], max_addr, device=local_rank, **crypto)
     p = ram.params
-    rng = np.random.default_rng(1234 + (0 if sharded else rank))     # sharded: every rank derives the same keys and address
     n_digits = p.base2d().as_1d().size()
-    keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(synth(rng, (12, 3 * s_evk * 2 * N))),
-                                      synth(rng, 4 * 5 * 2 * N), synth(rng, 4 * 5 * 2 * N))
-    addr = pkg.Address(p, list(synth(rng, (n_digits, p.ggsw_len()))))
-    rng = np.random.default_rng(4321 + rank)
-    ram.load_encrypted(synth(rng, (ws, ram.local_rows(), p.glwe_len())))
-    words = synth(rng, (ws, p.glwe_len()))
+    # sharded: every rank derives the same keys and address, and its own rows; replicas: a RAM of its own per rank
+    inp = make_inputs(p, ws, s_evk, n_digits, ram.local_rows(), 1234 + (0 if (sharded or mode == "single") else rank), 4321 + rank)
+    keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(inp["atk"]), inp["atk_inv"], inp["tsk"])
+    addr = pkg.Address(p, list(inp["addr"]))
+    ram.load_encrypted(inp["rows"])
+    words = inp["words"]
     ram.stage_words(words)
     if sharded:
         from fheram_amd.sharded import ShardedRam, TorchComm
@@ -480,9 +515,10 @@ def main():
 
     out = {
         "metric": f"encrypted RAM read ops/s + write ops/s at 2^{args.log_max_addr} entries; achieved HBM GB/s vs peak",
-        "value": raw_ops_per_s * weight,
+        "value": raw_ops_per_s,
         "unit": "RAM ops/s (1 read + 1 write[=rpw+write] per step)" + (
-            f"; an op on the {world}*2^{args.log_max_addr}-entry sharded RAM counts as {world} ops of the 2^{args.log_max_addr}-entry metric" if weight > 1 else ""),
+            f" of the ONE 2^{log_entries}-entry RAM sharded over the {world} GPUs (weak scaling: 2^{args.log_max_addr} entries per GPU; "
+            f"value(N) / value(1) = T(1) / T(N) is the weak-scaling efficiency)" if weight > 1 else ""),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "mode": mode, "vs_baseline": None, "dtype": "f64",
         "arithmetic": "exact integers mod 2^48+57345 carried in FP64 (error-free products); int32 limbs in HBM",
@@ -494,6 +530,9 @@ def main():
                                + ("; configs[4] sharding" if sharded else "") + ")",
                    "rams": n_rams, "rows_per_subram": cnt["rows"], "parallelism": par},
         "ram_ops_s_raw": raw_ops_per_s,
+        "ops_weighted_by_ram_size": (None if weight == 1 else
+                                     {"value": raw_ops_per_s * weight,
+                                      "what": f"information only: an op on the {world}*2^{args.log_max_addr}-entry RAM counted as {world} ops of the 2^{args.log_max_addr}-entry metric"}),
         "read_ops_s": n_rams * 1e3 / read_ms, "write_ops_s": n_rams * 1e3 / (rpw_ms + write_ms),
         "read_ms": read_ms, "read_prepare_write_ms": rpw_ms, "write_ms": write_ms,
         "per_op_split": {"what": "read_ms / read_prepare_write_ms / write_ms: a pass of the same K steps with one HIP-event pair per op "
@@ -561,7 +600,10 @@ def main():
             # PRIMARY roofline = the roof that binds this kernel: the FP64 vector ALU.  Every FP64 VALU instruction
             # (mul / add / fma / rndne: all issue at the FMA rate) is priced as one FMA slot = 2 FLOP, so that achieved
             # and peak are in the guide's TFLOP/s; frac = instruction rate / 39.3 T instr/s.
-            out["roofline"] = {"kernel": "fused trace step (ks_run<KS_TRACE,3,4,3,NCO=2> inside k_keyswitch_chain<3,4,3> / k_keyswitch<1,3,4,3,2,0>), one workgroup per ciphertext",
+            form = int(os.environ.get("FHERAM_CHAIN_Y", "2")[:1] or 2)
+            fname = {0: "ks_run<KS_TRACE,3,%d,3,NCO=2> (int32 limbs between steps)", 1: "ks_trace_y<%d> (Y form, limb-by-limb normalisation)",
+                     2: "ks_trace_z<%d> (Y form, closed-form normalisation, paired inverse transforms)"}[min(form, 2)] % s_evk
+            out["roofline"] = {"kernel": f"fused trace step {fname} inside k_keyswitch_chain<3,{s_evk},3,{min(form, 2)}>, one workgroup per ciphertext",
                                "bound": "valu_fp64", "achieved": 2 * ach, "peak": 2 * FP64_VALU_PEAK_TINSTR, "unit": "TFLOP/s",
                                "frac": ach / FP64_VALU_PEAK_TINSTR,
                                "achieved_T_fp64_instr_s": ach, "peak_T_fp64_instr_s": FP64_VALU_PEAK_TINSTR,
@@ -577,7 +619,7 @@ def main():
                                                  f"that is otherwise uninstrumented ({light['elapsed'] * 1e3 / args.steps:.3f} ms per step against "
                                                  f"{ms_per_step:.3f} in the timed region)") if lightly else "HIP events around every launch (all-classes pass)",
                                "launch_unit": "one trace step over the batch (a chain launch runs 6 or 12 of them: HIP-event time of the launch / its steps)",
-                               "chain_launch": ({"kernel": "k_keyswitch_chain<3,4,3>", "launches": chain["launches"],
+                               "chain_launch": ({"kernel": f"k_keyswitch_chain<3,{s_evk},3,{min(form, 2)}>", "launches": chain["launches"],
                                                  "avg_launch_ms": (light["chain"]["ms"] if lightly else chain["ms"]) / chain["launches"],
                                                  "avg_steps_per_launch": chain["blocks"] / chain["launches"] / blocks}
                                                 if chain["launches"] else None),
@@ -618,28 +660,50 @@ def main():
                                              "(not part of the timed region: the events add this much to a step)",
                                      "ms_per_step_instrumented": instr_elapsed * 1e3 / args.steps}
 
+    parity_failed = False
     if not args.no_cpu_baseline and world == 1 and mode == "single":   # reported baseline: rank 0 at N = 1 only
         # bounded sample (~10 s of CPU work at 2^18): the whole RAM, one step; beyond 2^18 one of the `ws` sub-RAMs, scaled by
         # ws (the reference processes them one after the other, ram.rs:187-190; prepare_inv is shared, <1 % of a write)
+        flags = oracle_native()
         whole = max_addr * ws <= (1 << 20)
         k = 1 if whole else ws
-        r, q, w = cpu_baseline(max_addr, ws if whole else 1, 99, 1, crypto)
+        (r, q, w), o1 = cpu_baseline(max_addr, ws, inp, 1, crypto, None if whole else 0)
         out["cpu_baseline"] = {"value": 2.0 / (k * (r + q + w)), "unit": "RAM ops/s", "cores": 1, "kind": "port",
                                "sample": "oracle (C++ exact-integer restatement), single thread, "
                                          + (f"the whole 2^{args.log_max_addr} x {ws}-byte RAM, one step: " if whole else
                                             f"1 of {ws} sub-RAMs of the 2^{args.log_max_addr} RAM, scaled x{ws}: ")
-                                         + f"read {r:.2f}s + read_prepare_write {q:.2f}s + write {w:.2f}s",
+                                         + f"read {r:.2f}s + read_prepare_write {q:.2f}s + write {w:.2f}s; the inputs of the GPU legs",
                                "read_ms": k * r * 1e3, "read_prepare_write_ms": k * q * 1e3, "write_ms": k * w * 1e3,
-                               "host_cpu": host_cpu()}
+                               "host_cpu": host_cpu(), "build": flags}
         cores = host_cores()
-        r, q, w = cpu_baseline(max_addr, ws, 99, cores, crypto)
+        (r, q, w), oa = cpu_baseline(max_addr, ws, inp, cores, crypto)
         out["cpu_baseline_allcores"] = {"value": 2.0 / (r + q + w), "unit": "RAM ops/s", "cores": cores, "kind": "port",
                                         "sample": f"oracle, OpenMP over the {ws} sub-RAMs and over the rows (per-row loops; packing level by level with "
-                                                  f"the leaves of a level in parallel), whole 2^{args.log_max_addr} RAM, one step",
-                                        "read_ms": r * 1e3, "read_prepare_write_ms": q * 1e3, "write_ms": w * 1e3, "host_cpu": host_cpu()}
+                                                  f"the leaves of a level in parallel), whole 2^{args.log_max_addr} RAM, one step; the inputs of the GPU legs",
+                                        "read_ms": r * 1e3, "read_prepare_write_ms": q * 1e3, "write_ms": w * 1e3, "host_cpu": host_cpu(),
+                                        "build": flags}
+        # Parity inside the run (examples/fhe-ram.rs:98-115 checks the result it has just timed): the context that was timed, its rows
+        # loaded again, runs the same step once more — untimed, results downloaded — and every output must equal the oracle's on
+        # the same inputs, bit for bit (SHA-256 of the int64 limbs).
+        ram.load_encrypted(inp["rows"])
+        g = {"read": ram.read(addr, keys), "rpw": ram.read_prepare_write(addr, keys)}
+        ram.write(words, addr, keys)
+        g["rows_after_write"] = ram.store_encrypted()
+        ram.stage_words(words)
+        par = {kk: bool(np.array_equal(g[kk], oa[kk])) for kk in ("read", "rpw", "rows_after_write")}
+        sel = slice(None) if whole else slice(0, 1)
+        par["single_thread_leg_agrees"] = all(bool(np.array_equal(np.asarray(g[kk])[sel], o1[kk])) for kk in ("read", "rpw", "rows_after_write"))
+        par["sha256"] = {kk: {"hip": sha(g[kk]), "oracle": sha(oa[kk])} for kk in ("read", "rpw", "rows_after_write")}
+        par["what"] = ("one more untimed step on the timed context (rows reloaded), results downloaded through the C ABI, against the oracle's "
+                       "all-core leg on the same keys, address, rows and words; bit-exact int64 limbs")
+        out["parity_in_run"] = par
+        parity_failed = not all(par[kk] for kk in ("read", "rpw", "rows_after_write", "single_thread_leg_agrees"))
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if parity_failed:
+        print("bench.py: PARITY FAILURE: the HIP path and the oracle differ on the run's own inputs (parity_in_run)", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

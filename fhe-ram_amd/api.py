@@ -110,6 +110,7 @@ _SYMBOLS = [
     ("fheram_profile_get", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     ("fheram_tail_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("fheram_mid_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("fheram_mid_state", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     ("fheram_profile_reset", C.c_int, [C.c_void_p]),
     ("fheram_bench_external_product", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("fheram_bench_chain", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -131,6 +132,8 @@ _SYMBOLS = [
     ("fheram_group_write", C.c_int, [C.c_void_p, I64P, C.c_int, C.c_void_p]),
     ("fheram_group_word_stage", C.c_int, [C.c_void_p, I64P, C.c_int]),
     ("fheram_group_result_download", C.c_int, [C.c_void_p, I64P]),
+    ("fheram_group_peer_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    ("fheram_group_poisoned", C.c_int, [C.c_void_p]),
     ("fheram_selftest_modarith", C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 6),
     ("fheram_selftest_ntt", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("fheram_selftest_constants", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -661,11 +664,20 @@ class Ram:
         return bool(library().fheram_ram_state(self._h))
 
     # -- the path
+    def _check_out(self, out):
+        """a caller-owned result buffer is written by the library (word_size * GLWE int64): refuse anything it could overrun"""
+        p = self.params
+        if not (isinstance(out, np.ndarray) and out.dtype == np.int64 and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]
+                and out.size == p.word_size() * p.glwe_len()):
+            raise FheRamError(1, f"out must be a writeable C-contiguous int64 array of {p.word_size()} x {p.glwe_len()} elements")
+
     def read(self, address: Address, keys: EvaluationKeysPrepared, download: bool = True, out=None):  # ram.rs:172
         """out: an int64 array [word_size][GLWE] to receive the result (a host that reads in a loop reuses one)"""
         self._use_keys(keys)
         if download and out is None:
             out = self._out()
+        elif download:
+            self._check_out(out)
         self._chk(library().fheram_read(self._h, address._device(self), _p(out) if download else None))
         return out if download else None
 
@@ -673,6 +685,8 @@ class Ram:
         self._use_keys(keys)
         if download and out is None:
             out = self._out()
+        elif download:
+            self._check_out(out)
         self._chk(library().fheram_read_prepare_write(self._h, address._device(self), _p(out) if download else None))
         return out if download else None
 
@@ -834,6 +848,12 @@ class Ram:
         self._chk(library().fheram_mid_stats(self._h, C.byref(a), C.byref(b)))
         return {"launches": int(a.value), "fallbacks": int(b.value)}
 
+    def mid_state(self):
+        """setting of the single-launch mid chains in effect (0: switched off by the path itself) and how often it has been"""
+        en, n = C.c_int(), C.c_uint64()
+        self._chk(library().fheram_mid_state(self._h, C.byref(en), C.byref(n)))
+        return {"enabled": int(en.value), "times_disabled": int(n.value)}
+
     def bench_external_product(self, batch: int, iters: int) -> float:
         """ms for a dependent chain of `iters` launches of `batch` GLWE x GGSW products (BASELINE.json configs[1])"""
         ms = C.c_float()
@@ -966,3 +986,16 @@ class GroupRam:
         out = self._out()
         self._chk(library().fheram_group_result_download(self._h, _p(out)))
         return out
+
+    def peer_info(self) -> List[bool]:
+        """per shard: the exchange copies between its device and the root's go peer to peer (the self-test copies of the
+        constructor went through either way)"""
+        n = len(self.devices)
+        d = (C.c_int * n)()
+        self._chk(library().fheram_group_peer_info(self._h, d, n))
+        return [bool(x) for x in d]
+
+    @property
+    def poisoned(self) -> bool:
+        """an op failed part-way: every further op is refused until load_encrypted has replaced the rows"""
+        return bool(library().fheram_group_poisoned(self._h))

@@ -141,6 +141,9 @@ struct fheram_ctx {
     unsigned mid_seq = 0;
     uint64_t mid_launches = 0, mid_launch_mark = 0;
     unsigned mid_fb_mark = 0;
+    int mid_bad_windows = 0, mid_saved = 0;          // auto-disable of the single-launch mid chains: consecutive bad windows; the setting to come back to
+    uint64_t mid_off_at = 0, mid_disabled_count = 0; // launch count when it was switched off; times it has been
+    unsigned mid_off_ops = 0;                        // ops since then (re-armed after 256)
     unsigned* h_mid_fb = nullptr;      // pinned, device-visible: ciphertexts redone, [0] main stream, [16] side stream
     unsigned* d_mid_sync[2] = {nullptr, nullptr};   // [64 groups][32] + [_, ciphertexts redone]: main / side stream
     double* d_mid_big[2] = {nullptr, nullptr};      // [step parity][ciphertext x RS <= 64] x BIG_STRIDE doubles: k_chain_mid's partial limb polynomials
@@ -150,6 +153,7 @@ struct fheram_ctx {
     //              address the write will use — starts them on the (low-priority) side stream next to its trace chain,
     //              which is one launch holding 24 CUs on half of the XCDs: the rest of the chip is idle then.  A write
     //              with another address, or after new keys, computes them itself.  FHERAM_PRE_INV=0: always.
+    int safe = 0;                  // FHERAM_SAFE=1: no in-kernel hand-offs between workgroups, no gate wave (fheram.hip)
     int pre_inv = 1;
     uint64_t inv_id[2] = {0, 0};
     double* d_prep_inv = nullptr;  // [n_digits] prepared GGSW

@@ -128,6 +128,13 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         // a captured launch sequence must be a pure function of (context, address, op): under replay the write always
         // computes its own inverse digits (whether a precompute matched is state the capture would freeze)
         if (c->use_graph) c->pre_inv = 0;
+        // FHERAM_SAFE=1: ONE switch for a configuration that stays inside the HIP memory model — no launch with in-kernel hand-offs
+        // between workgroups (k_trace_tail, k_chain_mid: relaxed agent-scope atomics + drained stores + L1-bypassing loads on one
+        // XCD's L2) and no gate wave (k_tail_gate): dependent steps are kernel boundaries, the side work forks from an event.
+        // Same results (tests/test_gpu_golden.py); priced in profiles/r04_bench_safe.json.
+        const char* sf = getenv("FHERAM_SAFE");
+        c->safe = (sf && sf[0] == '1') ? 1 : 0;
+        if (c->safe) { c->tail = 0; c->tail_test = 0; c->mid = 0; c->mid_test = 0; if (c->pre_inv == 1) c->pre_inv = 2; }
         const char* e = getenv("FHERAM_NCO");
         c->nco = (e && e[0] == '2') ? 2 : ((e && e[0] == '1') ? 1 : 0);
         hipDeviceProp_t prop;
@@ -695,6 +702,12 @@ int fheram_mid_stats(fheram_ctx* c, uint64_t* launches, uint64_t* fallbacks) {
     if (fallbacks) *fallbacks = (uint64_t)fb[0] + fb[1];
     return FHERAM_OK;
 }
+int fheram_mid_state(const fheram_ctx* c, int* enabled, uint64_t* times_disabled) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    if (enabled) *enabled = c->mid;
+    if (times_disabled) *times_disabled = c->mid_disabled_count;
+    return FHERAM_OK;
+}
 int fheram_tail_stats(fheram_ctx* c, uint64_t* launches, uint64_t* fallbacks) {
     if (!c) return FHERAM_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -752,6 +765,7 @@ int fheram_bench_external_product(fheram_ctx* c, int batch, int iters, float* to
 }
 int fheram_bench_chain(fheram_ctx* c, int kind, int batch, int n, int iters, float* total_ms) {
     if (!c || !total_ms || batch <= 0 || iters <= 0 || n < 1 || n > CHAIN_MAX || kind < 0 || kind > 1) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument");
+    if (kind == 1 && n > c->n_digits) return fail(c, FHERAM_ERR_INVALID_ARG, "a product chain is at most as long as the address has digits (d_prep holds n_digits prepared GGSWs)");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t G = fheram_ctx::GLWE;
     DevBuf da, db, dc, dg;
@@ -769,7 +783,7 @@ int fheram_bench_chain(fheram_ctx* c, int kind, int batch, int n, int iters, flo
             for (int i = 0; i < LOGN; i++) { c->cur = c->stream; launch_prepare(c, dg.p, c->d_atk + (size_t)i * c->atk, (int)(c->atk / N), c->gal[i]); }
     }
     c->cur = c->stream;
-    if (kind == 1) launch_prepare(c, dg.p, c->d_prep, n * (int)(fheram_ctx::GGSW / N));
+    if (kind == 1) launch_prepare(c, dg.p, c->d_prep, n * (int)(fheram_ctx::GGSW / N));   // (n <= n_digits: checked above)
     GlweRef ra = ref(da.p, 0, (long)G), rb = ref(db.p, 0, (long)G), rc = ref(dc.p, 0, (long)G);
     auto once = [&](int i) {
         GlweRef src = (i & 1) ? rb : ra, dst = (i & 1) ? ra : rb;

@@ -9,6 +9,7 @@
 // been recorded (a wait on an event that has not been recorded yet would be a no-op), through two atomics per op.
 // Results are bit-identical to the unsharded path: every packer combine sees the operands of the sequential packer.
 #pragma once
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -34,8 +35,14 @@ struct fheram_group {
     std::vector<std::unique_ptr<Worker>> w;
     std::vector<hipEvent_t> ev_part;   // [shard] recorded on the shard's stream after its partial has been copied to the root
     std::vector<hipEvent_t> ev_ctlo;   // [shard] recorded on the root's stream after ct_lo has been copied to the shard
-    std::atomic<int> parts_recorded{0}, ctlo_recorded{0};
+    std::atomic<int> parts_recorded{0}, ctlo_recorded{0}, ready{0};
     std::atomic<bool> failed{false};
+    // A group op that fails AFTER work has been enqueued leaves the shards inconsistent (rows half written, state flags and kept
+    // by-products of read_prepare_write out of step): the group is poisoned and every further op fails fast until the rows are
+    // uploaded again (fheram_group_ram_upload resets every shard).  Errors found BEFORE anything is enqueued (the reference's
+    // asserts: wrong state, foreign address, missing keys) are checked on the calling thread for every shard and poison nothing.
+    bool poisoned = false;
+    std::vector<char> peer_direct;     // [shard] 1: the self-test copy shard <-> root went through (fheram_group_peer_info)
     int root = 0;
     std::string err;
 
@@ -59,7 +66,10 @@ void worker_main(fheram_group::Worker* w, int device) {
         std::function<int()> job = std::move(w->job);
         w->has_job = false;
         lk.unlock();
-        const int rc = job();
+        int rc;
+        try { rc = job(); }                       // a job must never take the process down (bad_alloc in a staging vector, ...)
+        catch (const std::bad_alloc&) { rc = FHERAM_ERR_DEVICE; }
+        catch (...) { rc = FHERAM_ERR_DEVICE; }
         lk.lock();
         w->rc = rc;
         w->done = true;
@@ -83,17 +93,39 @@ int run_all(fheram_group* g, const std::function<int(int)>& job) {
     for (int i = 0; i < g->n(); i++) post(g->w[i].get(), [&job, i] { return job(i); });
     int rc = FHERAM_OK, who = -1;
     for (int i = 0; i < g->n(); i++) { const int r = wait(g->w[i].get()); if (r != FHERAM_OK && rc == FHERAM_OK) { rc = r; who = i; } }
-    if (rc != FHERAM_OK) g->err = "shard " + std::to_string(who) + ": " + g->ctx[who]->err;
+    if (rc != FHERAM_OK) g->err = "shard " + std::to_string(who) + ": " + (g->ctx[who]->err.empty() ? std::string("job failed (exception / out of memory)") : g->ctx[who]->err);
     return rc;
 }
 // bounded host-side wait for `want` recordings (the other workers are enqueueing at this very moment); gives up when a
 // peer failed, so that nobody waits for an event that will never be recorded
+constexpr int GROUP_WAIT_S = 30;   // the peers only ENQUEUE before they count (milliseconds); 30 s means one of them is gone
 bool await_count(fheram_group* g, std::atomic<int>& ctr, int want) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(GROUP_WAIT_S);
     for (long spin = 0; ctr.load(std::memory_order_acquire) < want; spin++) {
         if (g->failed.load(std::memory_order_acquire)) return false;
         if (spin > 64) std::this_thread::yield();
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() > deadline) { g->failed.store(true, std::memory_order_release); return false; }
     }
-    return true;
+    return !g->failed.load(std::memory_order_acquire);
+}
+// the reference's asserts, for every shard, on the calling thread, BEFORE anything is enqueued: a refused call changes nothing
+int group_precheck(fheram_group* g, const fheram_group_addr* ga, bool want_state, const char* state_msg) {
+    if (g->poisoned) return gfail(g, FHERAM_ERR_STATE, "the group is poisoned: an earlier op failed part-way and left the shards inconsistent; upload the rows again (fheram_group_ram_upload)");
+    for (int i = 0; i < g->n(); i++) {
+        fheram_ctx* c = g->ctx[i];
+        int rc = check_common(c, ga->a[i]);
+        if (rc == FHERAM_OK && c->state != want_state) rc = fail(c, FHERAM_ERR_STATE, state_msg);
+        if (rc != FHERAM_OK) { g->err = "shard " + std::to_string(i) + ": " + c->err; return rc; }
+    }
+    return FHERAM_OK;
+}
+// an op failed after its jobs had started: see fheram_group::poisoned
+int group_poison(fheram_group* g, int rc) {
+    if (rc == FHERAM_OK) return rc;
+    g->poisoned = true;
+    for (fheram_ctx* c : g->ctx) { hipSetDevice(c->device); write_side_abort(c); }
+    g->err += " [group poisoned: upload the rows again]";
+    return rc;
 }
 int check_group_addr(fheram_group* g, const fheram_group_addr* a) {
     if (!g) return FHERAM_ERR_INVALID_ARG;
@@ -108,26 +140,24 @@ int group_read_job(fheram_group* g, const fheram_group_addr* ga, bool prepare_wr
     const fheram_addr* addr = ga->a[i];
     const size_t part = (size_t)c->ws * fheram_ctx::GLWE;
     auto bail = [&](int rc) { g->failed.store(true, std::memory_order_release); return rc; };
-    int rc = check_common(c, addr);
-    if (rc == FHERAM_OK && c->state) rc = fail(c, FHERAM_ERR_STATE, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
-    if (rc != FHERAM_OK) return bail(rc);
+    int rc;
     if (hipSetDevice(c->device) != hipSuccess) return bail(fail(c, FHERAM_ERR_DEVICE, "hipSetDevice"));
     GlweRef packed;
     rc = read_local(c, addr, prepare_write, &packed, true);            // ... -> d_part
     if (rc != FHERAM_OK) return bail(rc);
-    if (prepare_write) c->state = true;                                    // ram.rs:533
+    // (ram.rs:533: the state flag is committed by the caller once EVERY shard has come through)
     hipError_t e = hipMemcpyPeerAsync(r->d_gat[0] + (size_t)i * part, r->device, c->d_part, c->device, part * sizeof(int32_t), c->stream);
     if (e == hipSuccess) e = hipEventRecord(g->ev_part[i], c->stream);
     if (e != hipSuccess) return bail(fail(c, FHERAM_ERR_DEVICE, std::string("partial -> root: ") + hipGetErrorString(e)));
     g->parts_recorded.fetch_add(1, std::memory_order_release);
     if (i != g->root) return FHERAM_OK;
     // root: the one exchange step of a read has been enqueued by everybody -> finish (top packer levels, coordinate 1, trace)
-    if (!await_count(g, g->parts_recorded, g->n())) return fail(c, FHERAM_ERR_DEVICE, "a shard failed before the exchange");
+    if (!await_count(g, g->parts_recorded, g->n())) return fail(c, FHERAM_ERR_DEVICE, "a shard failed (or did not arrive within 30 s) before the exchange");
     for (int k = 0; k < g->n(); k++)
         if (k != i && hipStreamWaitEvent(c->stream, g->ev_part[k], 0) != hipSuccess) return bail(fail(c, FHERAM_ERR_DEVICE, "hipStreamWaitEvent"));
     rc = read_top(c, addr, prepare_write, c->d_gat[0], ref(c->d_part, (long)fheram_ctx::GLWE, 0));
-    if (rc != FHERAM_OK) return rc;
-    if (hipGetLastError() != hipSuccess) return fail(c, FHERAM_ERR_DEVICE, "launch failure in read_top");
+    if (rc != FHERAM_OK) return bail(rc);
+    if (hipGetLastError() != hipSuccess) return bail(fail(c, FHERAM_ERR_DEVICE, "launch failure in read_top"));
     return out ? fheram_result_download(c, out) : fheram_sync(c);
 }
 
@@ -138,9 +168,7 @@ int group_write_job(fheram_group* g, const fheram_group_addr* ga, int i) {
     const fheram_addr* addr = ga->a[i];
     const size_t part = (size_t)c->ws * fheram_ctx::GLWE;
     auto bail = [&](int rc) { g->failed.store(true, std::memory_order_release); return rc; };
-    int rc = check_common(c, addr);
-    if (rc == FHERAM_OK && !c->state) rc = fail(c, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
-    if (rc != FHERAM_OK) return bail(rc);
+    int rc;
     if (hipSetDevice(c->device) != hipSuccess) return bail(fail(c, FHERAM_ERR_DEVICE, "hipSetDevice"));
     if (!c->side_begun) write_side_begin(c, addr);                        // trace(ct_hi) of the local rows, inverse of coordinate 0: no ct_lo needed
     if (i == g->root) {
@@ -155,13 +183,17 @@ int group_write_job(fheram_group* g, const fheram_group_addr* ga, int i) {
         }
         g->ctlo_recorded.store(1, std::memory_order_release);
     } else {
-        if (!await_count(g, g->ctlo_recorded, 1)) { write_side_abort(c); return fail(c, FHERAM_ERR_DEVICE, "the root failed before the exchange"); }
-        if (hipStreamWaitEvent(c->stream, g->ev_ctlo[i], 0) != hipSuccess) { write_side_abort(c); return fail(c, FHERAM_ERR_DEVICE, "hipStreamWaitEvent"); }
+        if (!await_count(g, g->ctlo_recorded, 1)) { write_side_abort(c); return fail(c, FHERAM_ERR_DEVICE, "the root failed (or did not arrive within 30 s) before the exchange"); }
+        if (hipStreamWaitEvent(c->stream, g->ev_ctlo[i], 0) != hipSuccess) { write_side_abort(c); return bail(fail(c, FHERAM_ERR_DEVICE, "hipStreamWaitEvent")); }
     }
     (void)r;
+    // second rendezvous: nobody touches its rows before EVERY shard has its ct_lo on the way — a shard that failed up to here
+    // leaves all rows as they were (the root included)
+    g->ready.fetch_add(1, std::memory_order_release);
+    if (!await_count(g, g->ready, g->n())) { write_side_abort(c); return fail(c, FHERAM_ERR_DEVICE, "a shard failed before the rows were written: no row has been changed"); }
     rc = write_rows(c, addr);                                             // write_mid_step on the local rows, write_last_step
-    if (rc != FHERAM_OK) return rc;
-    if (hipGetLastError() != hipSuccess) return fail(c, FHERAM_ERR_DEVICE, "launch failure in write_rows");
+    if (rc != FHERAM_OK) return bail(rc);
+    if (hipGetLastError() != hipSuccess) return bail(fail(c, FHERAM_ERR_DEVICE, "launch failure in write_rows"));
     return fheram_sync(c);                                                // the op is complete when every shard's rows are
 }
 
@@ -219,6 +251,36 @@ int fheram_group_create(const fheram_params* p, const int* devices, int n_device
             }
         }
     }
+    // self-test of the exchange path: one copy shard -> root and one root -> shard per shard, checked word for word.  A pair that
+    // cannot copy (no peer path, IOMMU / IPC restrictions) fails HERE, with the pair named, not in the middle of the first read.
+    g->peer_direct.assign(n_devices, 1);
+    {
+        fheram_ctx* r = g->ctx[g->root];
+        const size_t n_probe = 256;
+        std::vector<int32_t> pat(n_probe), back(n_probe);
+        for (int i = 0; i < n_devices; i++) {
+            fheram_ctx* c = g->ctx[i];
+            if (c == r) continue;
+            int can = 0;
+            g->peer_direct[i] = (devices[i] == devices[g->root]) ? 1 : ((hipDeviceCanAccessPeer(&can, devices[g->root], devices[i]) == hipSuccess && can) ? 1 : 0);
+            for (size_t k = 0; k < n_probe; k++) pat[k] = (int32_t)(0x5EED0000u + (unsigned)i * 4096u + (unsigned)k);
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipMemcpy(c->d_part, pat.data(), n_probe * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(r->d_gat[0], r->device, c->d_part, c->device, n_probe * 4, c->stream);      // shard -> root (read)
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipSetDevice(r->device);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(c->d_part + n_probe, c->device, r->d_gat[0], r->device, n_probe * 4, r->stream);  // root -> shard (write)
+            if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+            if (e == hipSuccess) e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipMemcpy(back.data(), c->d_part + n_probe, n_probe * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess || back != pat) {
+                g_group_err = "peer copy self-test failed between device " + std::to_string(devices[i]) + " (shard " + std::to_string(i) + ") and the root's device " +
+                              std::to_string(devices[g->root]) + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string(": data mismatch"));
+                fheram_group_destroy(g);
+                return FHERAM_ERR_DEVICE;
+            }
+        }
+    }
     for (int i = 0; i < n_devices; i++) {
         g->w.emplace_back(new fheram_group::Worker());
         g->w.back()->th = std::thread(worker_main, g->w.back().get(), devices[i]);
@@ -226,6 +288,14 @@ int fheram_group_create(const fheram_params* p, const int* devices, int n_device
     *out = g;
     return FHERAM_OK;
 }
+/* per shard: 1 = the exchange copies between the shard's device and the root's go peer to peer (or are on one device), 0 = the
+ * runtime stages them (hipDeviceCanAccessPeer says no); the self-test copy of fheram_group_create went through either way */
+int fheram_group_peer_info(const fheram_group* g, int* direct, int n) {
+    if (!g || !direct || n < g->n()) return FHERAM_ERR_INVALID_ARG;
+    for (int i = 0; i < g->n(); i++) direct[i] = g->peer_direct[i];
+    return FHERAM_OK;
+}
+int fheram_group_poisoned(const fheram_group* g) { return (g && g->poisoned) ? 1 : 0; }
 
 /* EvaluationKeysPrepared::prepare on every shard (keys are replicated; keys.rs:57-71) */
 int fheram_group_keys_load(fheram_group* g, const int64_t* gal_els, int n_gal, const int64_t* const* atk_glwe,
@@ -239,14 +309,17 @@ int fheram_group_ram_upload(fheram_group* g, const int64_t* rows) {
     if (!g) return FHERAM_ERR_INVALID_ARG;
     if (!rows) return gfail(g, FHERAM_ERR_INVALID_ARG, "null rows");
     const size_t G = fheram_ctx::GLWE;
-    return run_all(g, [&](int i) -> int {
+    const int rc = run_all(g, [&](int i) -> int {
         fheram_ctx* c = g->ctx[i];
         std::vector<int64_t> mine((size_t)c->ws * c->rows * G);
         for (int y = 0; y < c->ws; y++)
             for (size_t x = 0; x < c->rows; x++)
                 std::memcpy(&mine[((size_t)y * c->rows + x) * G], rows + ((size_t)y * c->rows_glob + (size_t)i + x * g->n()) * G, G * sizeof(int64_t));
-        return fheram_ram_upload(c, mine.data());
+        write_side_abort(c);
+        return fheram_ram_upload(c, mine.data());     // resets state and the kept by-products of read_prepare_write
     });
+    if (rc == FHERAM_OK) g->poisoned = false;         // every shard holds consistent rows again
+    return rc;
 }
 int fheram_group_ram_download(fheram_group* g, int64_t* rows) {
     if (!g) return FHERAM_ERR_INVALID_ARG;
@@ -299,16 +372,22 @@ int fheram_group_read(fheram_group* g, const fheram_group_addr* addr, int64_t* o
     int rc = check_group_addr(g, addr);
     if (rc != FHERAM_OK) return rc;
     if (g->n() == 1) { rc = fheram_read(g->ctx[0], addr->a[0], out); if (rc != FHERAM_OK) g->err = g->ctx[0]->err; else if (!out) rc = fheram_sync(g->ctx[0]); return rc; }
+    rc = group_precheck(g, addr, false, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
+    if (rc != FHERAM_OK) return rc;
     g->parts_recorded.store(0); g->failed.store(false);
-    return run_all(g, [&](int i) { return group_read_job(g, addr, false, out, i); });
+    return group_poison(g, run_all(g, [&](int i) { return group_read_job(g, addr, false, out, i); }));
 }
 /* Ram::read_prepare_write (ram.rs:196-222) */
 int fheram_group_read_prepare_write(fheram_group* g, const fheram_group_addr* addr, int64_t* out) {
     int rc = check_group_addr(g, addr);
     if (rc != FHERAM_OK) return rc;
     if (g->n() == 1) { rc = fheram_read_prepare_write(g->ctx[0], addr->a[0], out); if (rc != FHERAM_OK) g->err = g->ctx[0]->err; else if (!out) rc = fheram_sync(g->ctx[0]); return rc; }
+    rc = group_precheck(g, addr, false, "invalid call to Memory.read: internal state is true -> requires calling Memory.write");
+    if (rc != FHERAM_OK) return rc;
     g->parts_recorded.store(0); g->failed.store(false);
-    return run_all(g, [&](int i) { return group_read_job(g, addr, true, out, i); });
+    rc = group_poison(g, run_all(g, [&](int i) { return group_read_job(g, addr, true, out, i); }));
+    if (rc == FHERAM_OK) for (fheram_ctx* c : g->ctx) c->state = true;      // ram.rs:533, on every shard or on none
+    return rc;
 }
 /* Ram::write (ram.rs:226-294); w == NULL uses the words staged by fheram_group_word_stage */
 int fheram_group_write(fheram_group* g, const int64_t* w, int n_w, const fheram_group_addr* addr) {
@@ -317,11 +396,12 @@ int fheram_group_write(fheram_group* g, const int64_t* w, int n_w, const fheram_
     fheram_ctx* r = g->ctx[g->root];
     if (n_w != r->ws) return gfail(g, FHERAM_ERR_INVALID_ARG, "w.len() != subrams.len() (ram.rs:243)");
     if (g->n() == 1) { rc = fheram_write(r, w, n_w, addr->a[0]); if (rc != FHERAM_OK) g->err = r->err; else rc = fheram_sync(r); return rc; }
-    if (!r->state) return gfail(g, FHERAM_ERR_STATE, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
+    rc = group_precheck(g, addr, true, "invalid call to Memory.write: internal state is false -> requires calling Memory.read_prepare_write");
+    if (rc != FHERAM_OK) return rc;
     if (w) { rc = fheram_word_stage(r, w, n_w); if (rc != FHERAM_OK) { g->err = r->err; return rc; } }
     else if (!r->words_staged) return gfail(g, FHERAM_ERR_INVALID_ARG, "w == NULL and no staged words");
-    g->ctlo_recorded.store(0); g->failed.store(false);
-    return run_all(g, [&](int i) { return group_write_job(g, addr, i); });
+    g->ctlo_recorded.store(0); g->ready.store(0); g->failed.store(false);
+    return group_poison(g, run_all(g, [&](int i) { return group_write_job(g, addr, i); }));
 }
 int fheram_group_result_download(fheram_group* g, int64_t* out) {
     if (!g) return FHERAM_ERR_INVALID_ARG;

@@ -1294,6 +1294,12 @@ __device__ __forceinline__ void fold_limb(double (&od)[E], double (&ec)[E], cons
 #ifndef FK_Z_SKEW
 #define FK_Z_SKEW 1          // ks_trace_z: the two inverse transforms of a batch half a phase apart (ntt_inv2_skew)
 #endif
+#ifndef FK_Z_SKEW_ODD
+#define FK_Z_SKEW_ODD 0
+#endif
+#ifndef FK_Z_UNROLL_PAIRS
+#define FK_Z_UNROLL_PAIRS 0
+#endif
 #ifndef FK_Z_UNROLL_COLS
 #define FK_Z_UNROLL_COLS 1
 #endif
@@ -1405,6 +1411,64 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
 #pragma unroll
         for (int k = 0; k < E; k++) ec[k] = 0.0;
         fetch(SK - 1, co, PF, SX);   // (the first PF polynomials were requested in front of the forward transforms / of column 1's last transforms)
+        if constexpr ((SK & 1) && FK_Z_BI == 2) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
+        // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
+        auto batch = [&](auto nb_tag, int j) {
+            constexpr int NB = decltype(nb_tag)::value;
+            double acc[NB][E];
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
+            // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
+#pragma unroll
+            for (int r = 0; r < SX; r++) {
+                mac_regs(acc[0], xh[r], g[r]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NB == 2) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (NB == 2) {
+#pragma unroll
+                for (int r = 0; r < SX; r++) mac_regs(acc[NB - 1], xh[r], g[r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next limbs' first operands (or the next column's): requested HERE, their fetch runs under the transforms
+            if constexpr (PF > 0) {
+                if (j >= NB) fetch(j - NB, co, 0, PF);
+                else if (ci == 0) fetch(SK - 1, 0, 0, PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
+            if constexpr (NB == 2) {
+                if constexpr (FK_Z_SKEW_ODD) ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);   // (5-limb keys: six spilled registers with the skewed pair, none without)
+                else ntt_inv<2, true, false>(acc, tw, data, tid);
+                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+                fold_limb<SK>(od, ec, acc[0], j);
+                fold_limb<SK>(od, ec, acc[NB - 1], j - 1);
+            } else {
+                ntt_inv<1, true, false>(acc, tw, data, tid);
+                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+                fold_limb<SK>(od, ec, acc[0], j);
+            }
+            if constexpr (PF < SX) {   // the rest of the next limb's operands: their fetch runs under the fold and the first products
+                if (j >= NB) fetch(j - NB, co, PF, SX);
+            }
+            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
+        };
+        if constexpr (FK_Z_BI == 2) {
+#if FK_Z_UNROLL_PAIRS
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+            for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
+            if constexpr (SK & 1) batch(std::integral_constant<int, 1>{}, 0);
+        } else {
+#pragma unroll 1
+            for (int j = SK - 1; j >= 0; j--) batch(std::integral_constant<int, 1>{}, j);
+        }
+        } else {
 #pragma unroll 1
         for (int j = SK - 1; j >= 0; j -= FK_Z_BI) {
             const bool two = FK_Z_BI == 2 && j >= 1;
@@ -1451,6 +1515,7 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
             }
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         }
+        }
 #pragma unroll
         for (int k = 0; k < E; k++) {
             double a_ = window51(od[k]);
@@ -1467,6 +1532,193 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
         }
     }
     YSTAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------
+// ep_run_z (round 4): the external product of a product chain with the normalisation in closed form (see ks_trace_z):
+// res = normalize_{4 -> 3 limbs}(sum_j big_j) is the balanced digit vector of
+//        V = carry(big_3) + big_2 + cmod(big_1, 2^34) * 2^17 + cmod(big_0, 2^17) * 2^34      modulo 2^51,
+// so the output limbs of a column are independent of each other: inverse transforms in skewed pairs (ntt_inv2_skew), one
+// accumulator per coefficient instead of a carry chain.  Inside a chain the intermediate ciphertexts travel as
+// A = window51(V), ONE double per coefficient and column ([col][N] in the ciphertext's slot; k_chain_mid's products do
+// the same): the consumer takes its three digits from A in FP64 (no int32 limbs, no conversions between steps).
+//   IN_A  : the input is in that form (else an int32 GLWE)       OUT_A : the output is written in that form
+// ---------------------------------------------------------------------------------------
+#ifndef FK_EPZ_PARK
+#define FK_EPZ_PARK 1
+#endif
+#ifndef FK_EPZ_SKEW
+#define FK_EPZ_SKEW 1
+#endif
+#ifndef FK_EPZ_UNROLL_COLS
+#define FK_EPZ_UNROLL_COLS 0
+#endif
+template <int SG, bool IN_A, bool OUT_A>
+__device__ __forceinline__ void ep_run_z(GlweRef a, GlweRef res, const double* __restrict__ ggsw, const double* __restrict__ tw_g,
+                                         double* lds, bool load_tw, const int tid, const bool stamp_on = false) {
+    YSTAMP(0);
+    constexpr int SA = 3;
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    TwRegs twr;
+    if (load_tw) twiddles_issue(twr, tw_g, tid);
+    const int32_t* ap = at(a);
+    int32_t* rp = at(res);
+    double x0[SA][E], x1[SA][E];   // digits of column 0 / column 1 of a
+    OpRegs g[SA];
+    auto load_digits = [&](int col, double (&x)[SA][E]) {
+        if constexpr (IN_A) {
+            const double* yp = reinterpret_cast<const double*>(ap) + (long)col * N;
+            double av[E];
+#pragma unroll
+            for (int k = 0; k < E; k++) av[k] = gload_f64(yp, (unsigned)(tid + T * k) * 8u);
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                double c = av[k];
+                x[2][k] = take_digit(c);
+                x[1][k] = take_digit(c);
+                x[0][k] = c;            // A lies in the digit window: the second quotient IS the top digit
+            }
+        } else {
+            int xi[SA][E];
+#pragma unroll
+            for (int r = 0; r < SA; r++)
+#pragma unroll
+                for (int k = 0; k < E; k++) xi[r][k] = gload_i32(ap + glwe_off(r, col), (unsigned)(tid + T * k) * 4u);
+#pragma unroll
+            for (int r = 0; r < SA; r++)
+#pragma unroll
+                for (int k = 0; k < E; k++) x[r][k] = (double)xi[r][k];
+        }
+    };
+    load_digits(0, x0);
+    if (load_tw) twiddles_commit(twr, tw, tid);
+    YSTAMP(1);
+    fwd_all<SA>(x0, tw, data, tid);
+    YSTAMP(2);
+    load_digits(1, x1);
+    fwd_all<SA>(x1, tw, data, tid);
+    YSTAMP(3);
+    // x1's last polynomial waits in the third exchange buffer (this wave's own region of it: see ks_trace_z), 16 registers
+    // fewer during the limb loops; the products read it back from there
+    double* park = data + 2 * LDS_DATA + (tid >> 6) * (64 * (E + 1)) + (tid & 63);
+    if constexpr (FK_EPZ_PARK) {
+#pragma unroll
+        for (int k = 0; k < E; k++) park[64 * k] = x1[SA - 1][k];
+    }
+    auto mac_x1 = [&](double (&acc_)[E], int r) {
+        if (FK_EPZ_PARK && r == SA - 1) {
+            double xp[E];
+#pragma unroll
+            for (int k = 0; k < E; k++) xp[k] = park[64 * k];
+            mac_regs(acc_, xp, g[r]);
+        } else mac_regs(acc_, x1[r], g[r]);
+    };
+
+    // operand polynomial (cin, r) of output limb j, column co
+    auto opnd = [&](int cin, int r, int j, int co) { return ggsw + (long)(((2 * r + cin) * SG + j) * 2 + co) * N; };
+#if FK_EPZ_UNROLL_COLS
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+    for (int co = 0; co < 2; co++) {
+        double od[E], ec[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) { od[k] = 0.0; ec[k] = 0.0; }
+#pragma unroll
+        for (int r = 0; r < SA; r++) load_ops(g[r], opnd(0, r, SG - 1, co), tid);
+#pragma unroll 1
+        for (int j = SG - 1; j >= 0; j -= 2) {
+            const bool two = j >= 1;
+            double acc[2][E];
+#pragma unroll
+            for (int k = 0; k < E; k++) { acc[0][k] = 0.0; acc[1][k] = 0.0; }
+            // 12 operand polynomials per pair of limbs through three register sets: each set is refilled with the polynomial
+            // three places further on as soon as its product has been taken
+#pragma unroll
+            for (int r = 0; r < SA; r++) {
+                mac_regs(acc[0], x0[r], g[r]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_ops(g[r], opnd(1, r, j, co), tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < SA; r++) {
+                mac_x1(acc[0], r);
+                __builtin_amdgcn_sched_barrier(0);
+                if (two) load_ops(g[r], opnd(0, r, j - 1, co), tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (two) {
+#pragma unroll
+                for (int r = 0; r < SA; r++) {
+                    mac_regs(acc[1], x0[r], g[r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_ops(g[r], opnd(1, r, j - 1, co), tid);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < SA; r++) mac_x1(acc[1], r);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            YSTAMP(8 + (co * SG + (SG - 1 - j)) * 4);
+            if (two) {
+                if constexpr (FK_EPZ_SKEW) ntt_inv2_skew<true, true>(acc, tw, data, data + LDS_DATA, tid);
+                else ntt_inv<2, true, true>(acc, tw, data, tid);
+                YSTAMP(9 + (co * SG + (SG - 1 - j)) * 4);
+                if (j >= 2) {
+#pragma unroll
+                    for (int r = 0; r < SA; r++) load_ops(g[r], opnd(0, r, j - 2, co), tid);
+                }
+                fold_limb<SG>(od, ec, acc[0], j);
+                fold_limb<SG>(od, ec, acc[1], j - 1);
+            } else {
+                ntt_inv<1, true, true>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
+                fold_limb<SG>(od, ec, acc[0], j);
+            }
+            YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            double a_ = window51(od[k]);
+            if constexpr (OUT_A) {
+                gstore_f64(reinterpret_cast<double*>(rp) + (long)co * N, (unsigned)(tid + T * k) * 8u, a_);
+            } else {
+                const double d2 = take_digit(a_);
+                const double d1 = take_digit(a_);
+                gstore_i32(rp + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
+                gstore_i32(rp + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
+                gstore_i32(rp + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
+            }
+        }
+    }
+    YSTAMP(5);
+}
+// the product chain in that form (n >= 2: the first step reads an int32 GLWE, the last one writes one)
+template <int SG>
+__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_ext_product_chain_z(EpChainArgs ca) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (ca.done) {
+        if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
+        if (threadIdx.x == 0) {
+            const unsigned taken = atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u) + 1u;   // ciphertexts redone (fheram_mid_stats)
+            if (ca.host_count) __hip_atomic_store(ca.host_count, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    GlweRef in = ca.src;
+#pragma unroll 1
+    for (int i = 0; i < ca.n; i++) {
+        const GlweRef out = ca.buf[i & 1];
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));   // see k_ext_product_chain
+        __builtin_assume(tid >= 0 && tid < T);
+        if (i == 0) ep_run_z<SG, false, true>(in, out, ca.ggsw[i], ca.tw, lds, true, tid);
+        else if (i + 1 < ca.n) ep_run_z<SG, true, true>(in, out, ca.ggsw[i], ca.tw, lds, false, tid, YSTAMP_STEP(i + 1));
+        else ep_run_z<SG, true, false>(in, out, ca.ggsw[i], ca.tw, lds, false, tid);
+        __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
+        in = out;
+    }
 }
 
 // GLWE::trace(start, start + n) (ram.rs:457,540,572,616,621 and the packer levels in which every

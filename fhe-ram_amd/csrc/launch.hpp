@@ -139,9 +139,18 @@ void fill_mid(fheram_ctx* c, MidArgs& ma, GlweRef src, GlweRef dst, int n, int g
     ma.src = src; ma.dst = dst; ma.tw = c->d_tw; ma.big = c->d_mid_big[side]; ma.sync = c->d_mid_sync[side]; ma.y = c->d_mid_y[side];
     if (++c->mid_seq == 0) ++c->mid_seq;
     c->mid_launches++;
-    if (!c->mid_test && c->mid_launches - c->mid_launch_mark >= 64) {   // as the tail: a context that keeps losing its CUs to others stops asking
-        const unsigned fb = ((volatile unsigned*)c->h_mid_fb)[0] + ((volatile unsigned*)c->h_mid_fb)[16];
-        if (fb - c->mid_fb_mark > 16) c->mid = 0;      // takes effect from the next chain on
+    // A context that keeps losing its CUs to others stops asking — for a while.  The fallback launch mirrors the number of
+    // ciphertexts it had to redo into a pinned host word (read without a synchronisation: a stale value only delays the
+    // decision by a window); what is counted here are WINDOWS of 64 launches in which more than 16 launches' worth of
+    // ciphertexts (on average a quarter) were redone: one contended launch — up to 64 ciphertexts at once — no longer switches
+    // the path off, two bad windows in a row do, and 1024 launches later the single-launch form is tried again.
+    if (!c->mid_test && c->mid_launches - c->mid_launch_mark >= 64) {
+        const unsigned fb = __atomic_load_n(c->h_mid_fb, __ATOMIC_RELAXED) + __atomic_load_n(c->h_mid_fb + 16, __ATOMIC_RELAXED);
+        const unsigned redone = fb - c->mid_fb_mark;
+        const unsigned cts = (unsigned)(gx * gy);
+        const bool bad = redone > 16u * (cts ? cts : 1u) / 4u + 16u;   // more than a quarter of 64 launches' ciphertexts
+        c->mid_bad_windows = bad ? c->mid_bad_windows + 1 : 0;
+        if (c->mid && c->mid_bad_windows >= 2) { c->mid_saved = c->mid; c->mid = 0; c->mid_off_at = c->mid_launches; c->mid_disabled_count++; }
         c->mid_fb_mark = fb;
         c->mid_launch_mark = c->mid_launches;
     }

@@ -45,6 +45,9 @@ int run_op(fheram_ctx* c, const fheram_addr* addr, int which, F&& enqueue) {
 }
 
 int check_common(fheram_ctx* c, const fheram_addr* addr) {
+    // the single-launch mid chains, switched off because their launches kept giving up (launch.hpp fill_mid), are tried again
+    // 256 ops later: a neighbour that held the CUs for a while does not cost the path its faster form for the context's life
+    if (c && !c->mid && c->mid_saved && ++c->mid_off_ops >= 256) { c->mid = c->mid_saved; c->mid_saved = 0; c->mid_bad_windows = 0; c->mid_off_ops = 0; }
     if (!c) return FHERAM_ERR_INVALID_ARG;
     if (!addr || addr->ctx != c) return fail(c, FHERAM_ERR_INVALID_ARG, "address does not belong to this context (layout mismatch, ram.rs:404)");
     if (!c->initialized) return fail(c, FHERAM_ERR_UNINITIALIZED, "unitialized memory: self.data.len()=0");

@@ -191,6 +191,15 @@ int fheram_group_read_prepare_write(fheram_group* grp, const fheram_group_addr* 
 int fheram_group_write(fheram_group* grp, const int64_t* w, int n_w, const fheram_group_addr* addr);   /* ram.rs:226-294; w == NULL: staged words */
 int fheram_group_word_stage(fheram_group* grp, const int64_t* w, int n_w);
 int fheram_group_result_download(fheram_group* grp, int64_t* out);
+/* Exchange path of the group (round 4).  fheram_group_create runs one self-test copy per shard in both directions (shard -> root as a
+ * read's partial pack, root -> shard as a write's ct_lo) and fails with FHERAM_ERR_DEVICE, naming the pair, if the bytes do not arrive.
+ * direct[i] = 1: the runtime reports a peer-to-peer path between shard i's device and the root's (or they are one device); 0: staged. */
+int fheram_group_peer_info(const fheram_group* grp, int* direct, int n);
+/* 1 after a group op failed part-way (work had been enqueued on some shard): rows and state flags of the shards are inconsistent,
+ * every further op returns FHERAM_ERR_STATE until fheram_group_ram_upload has replaced the rows.  Calls the reference would refuse
+ * with an assert (wrong state, foreign address, ram.rs:393-396,404,472-475,555-558) are refused before anything is enqueued and
+ * poison nothing. */
+int fheram_group_poisoned(const fheram_group* grp);
 
 /* ---- Poulpy-level operations reached from the path, exposed for
  * parity tests and micro-benchmarks.  Inputs/outputs are host buffers in the layouts above. */
@@ -250,7 +259,14 @@ int fheram_address_download(fheram_ctx* ctx, const fheram_addr* addr, int64_t* o
 int fheram_keys_encrypt_sk(fheram_ctx* ctx, const fheram_secret* sk, const int64_t* mask, const int64_t* noise,
                            int64_t* std_out);
 
-/* ---- Address::set_from_fheuint (conversion.rs:18-82).  The reference derives every address
+/* ---- Address::set_from_fheuint (conversion.rs:18-82).
+ * *** CONTRACT-COMPATIBLE ONLY — THE INPUT LAYOUT IS NOT poulpy-schemes' ***  A Rust host cannot hand its own FheUintPrepared
+ * to fheram_fheuint_create: poulpy-schemes 0.3.3 is un-vendored (Cargo.toml:10), so neither the memory layout of
+ * FheUintPrepared nor the algorithm of scalar_to_ggsw_blind_rotation could be read; the type below is this library's own.  What
+ * these entry points guarantee is the reference test's contract (conversion.rs:100-220): digit d decrypts to
+ * X^{((k >> bit_rsh) mod 2^bit_mask) << bit_lsh} on the gadget within the test's noise bound.  tools/poulpy_kat (feature
+ * kat_fheuint) exports a real FheUintPrepared and one derived digit for the first Rust-equipped run to compare against.
+ * The reference derives every address
  * digit from an encrypted integer with poulpy-schemes' scalar_to_ggsw_blind_rotation (un-vendored); what is built
  * here is its CONTRACT (conversion.rs:41-65 and the test at :100-220), by CMux chains on noiseless GGSW rows with
  * the external-product kernels — a self-consistent restatement, bit-exact against the in-repo oracle only.
@@ -292,6 +308,10 @@ int fheram_tail_stats(fheram_ctx* ctx, uint64_t* launches, uint64_t* fallbacks);
  * hand-offs too (k_chain_mid).  Each ciphertext's workgroups stand alone there: fallbacks = CIPHERTEXTS redone by the fused
  * launch behind (0 on a GPU the context has to itself). */
 int fheram_mid_stats(fheram_ctx* ctx, uint64_t* launches, uint64_t* fallbacks);
+/* enabled: the FHERAM_MID setting in effect (0 = the path has switched the single-launch mid chains off because their launches kept
+ * giving up — two windows of 64 launches in a row with more than a quarter of the ciphertexts redone — and will try them again
+ * 256 ops later); times_disabled: how often that has happened on this context */
+int fheram_mid_state(const fheram_ctx* ctx, int* enabled, uint64_t* times_disabled);
 /* BASELINE.json configs[1]: one GLWE x GGSW external product at N = 4096 on device-resident synthetic
  * operands (normalised limbs; the work is data independent).  Runs `iters` launches of `batch` products
  * back to back on the context's stream, each launch consuming the previous one's output (a dependent

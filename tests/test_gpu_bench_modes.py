@@ -78,3 +78,16 @@ def test_bench_native_group_mode_on_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = last_json(r.stdout)
     assert out["mode"] == "group" and out["n_gpus"] == 2 and out["value"] > 0 and "MAX_ADDR=2^14" in out["config"]["workload"]
+
+
+def test_scale_check_rehearsal_on_one_gpu():
+    """tools/scale_check.sh — the one command for the first contact with an 8-GPU node (digests through the native group and
+    through one process per GPU, then bench.py in both modes, N = 1/2/4/8) — rehearsed on the one GPU of the test box: every
+    shard on device 0, gloo instead of RCCL, the 2^18 digests (the 2^21 ones through 8 shards: test_gpu_golden.py), the
+    process-per-GPU legs up to N = 4 (the box admits 6 GPU processes)."""
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_check.sh")],
+                       env=dict(os.environ, REHEARSE="1", LOG="18", STEPS="2", WARM="1", RANKS_MAX="4"), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "every digest reproduced at every N" in r.stdout
+    lines = [l for l in r.stdout.splitlines() if l[:1].isdigit()]
+    assert len(lines) == 4 + 3 and all("FAILED" not in l for l in lines), r.stdout

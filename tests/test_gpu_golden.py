@@ -68,9 +68,9 @@ def test_hip_flow_matches_committed_digests(po, key):
 
 @pytest.mark.parametrize("env", [{"FHERAM_LIMB_SPLIT": "0", "FHERAM_NCO": "1"}, {"FHERAM_LIMB_SPLIT": "0", "FHERAM_NCO": "2", "FHERAM_CHAIN": "0"},
                                  {"FHERAM_FINE_SPLIT": "0"}, {"FHERAM_MEMO": "0"}, {"FHERAM_GRAPH": "1"}, {"FHERAM_TAIL": "2"},
-                                 {"FHERAM_CHAIN_Y": "0"}, {"FHERAM_PRE_INV": "0"}],
+                                 {"FHERAM_CHAIN_Y": "0"}, {"FHERAM_PRE_INV": "0"}, {"FHERAM_CHAIN_Y": "1"}, {"FHERAM_SAFE": "1"}],
                          ids=["column-split", "fused-unchained", "limb-parallel", "write-recomputes", "hipgraph-replay", "tail-gives-up",
-                              "limb-handover", "write-inverts"])
+                              "limb-handover", "write-inverts", "limb-by-limb-normalisation", "safe-no-inkernel-handoffs"])
 def test_forced_decompositions_reproduce_the_2_18_digests(env):
     """The launch heuristics are tuned on one chip shape and one RAM size; every alternative decomposition is forced at 2^14
     in test_gpu_parity.py — and here at the FULL size of BASELINE.json configs[2..3] (256 ciphertexts per round: the fused chain
@@ -154,6 +154,15 @@ def test_sharded_flow_matches_committed_digests(po, n_shards, max_addr, device_b
         shards[0].device_free(ctlo_ptr)
 
 
+class _Foreign:
+    """stands in for an Address and hands a group ANOTHER group's device address (what a host bug would do)"""
+    def __init__(self, handle):
+        self._handle = handle
+
+    def _group(self, grp):
+        return self._handle
+
+
 @pytest.mark.parametrize("n_devices,key", [(8, 1 << 21), (8, 1 << 18), (2, 1 << 14), (4, "readme_262144")])
 def test_native_group_matches_committed_digests(po, n_devices, key):
     """fheram_group_* (include/fheram.h): ONE handle, one call per op as the reference's Ram (ram.rs:172-176,196-200,
@@ -173,6 +182,8 @@ def test_native_group_matches_committed_digests(po, n_devices, key):
     with pytest.raises(pkg.FheRamError) as e:        # ram.rs:393-396
         grp.read(addr, keys)
     assert e.value.code == 2
+    assert not grp.poisoned and grp.state        # a refused call (the reference's assert) is refused before anything is enqueued
+    assert grp.peer_info() == [True] * n_devices   # the self-test copies of the constructor went through (one device here)
     grp.write(inp["w"], addr, keys)
     assert not grp.state
     out["rows_after_write"] = sha(grp.store_encrypted())
@@ -193,3 +204,10 @@ def test_native_group_matches_committed_digests(po, n_devices, key):
     grp.stage_words(inp["w"])
     grp.write(None, addr, keys)
     assert np.array_equal(grp.store_encrypted(), ram.store_encrypted())
+    # an address of another group is refused without side effects; rows uploaded again start a fresh, consistent RAM
+    other = pkg.GroupRam(params, [0] * 2)
+    with pytest.raises(pkg.FheRamError) as e:        # ram.rs:404: the address of another RAM
+        grp.read(_Foreign(pkg.Address(params, list(inp["addr"]))._group(other)), keys)
+    assert e.value.code == 1 and not grp.poisoned
+    grp.load_encrypted(inp["rows"])
+    assert not grp.state and sha(grp.read(addr, keys)) == d["outputs"]["read"]

@@ -167,6 +167,30 @@ fn main() {
     out.put("ggsw_inv_in", &[raw_ggsw(digit0).len()], raw_ggsw(digit0));
     out.put("ggsw_inv_out", &[raw_ggsw(&inv).len()], raw_ggsw(&inv));
 
+    // (6) N4: Address::set_from_fheuint (conversion.rs:68-82) — needs poulpy-schemes (Cargo feature `kat_fheuint`).  The evaluator's
+    //     fheram_fheuint_* entry points are CONTRACT-compatible only: their FheUintPrepared is an invented layout (one 5-limb GGSW per
+    //     bit, LSB first, k = K_EVK_GGSW_INV, dnum 4: include/fheram.h) and their digits come from CMux chains, not from
+    //     scalar_to_ggsw_blind_rotation.  These vectors show how far that is from the real thing: (a) the raw buffer and layout
+    //     infos of a real FheUintPrepared<u32> (is it one GGSW per bit at all? which k / dnum / bit order?), (b) ONE address digit
+    //     derived by the reference from it (does the digit the evaluator derives for the same integer decrypt to the same
+    //     X^{...}? — bit parity cannot be expected: the two algorithms accumulate different noise).
+    #[cfg(feature = "kat_fheuint")]
+    {
+        use poulpy_schemes::tfhe::bdd_arithmetic::FheUintPrepared;
+        let k_value: u32 = 0x1234_5678 % params.max_addr() as u32;
+        let ggsw_k_infos = params.ggsw_infos();                                              // ADAPT: the layout conversion.rs' test gives its fheuint (:70-83)
+        let mut fheuint: FheUintPrepared<Vec<u8>, u32, BackendImpl> = FheUintPrepared::alloc_from_infos(module, &ggsw_k_infos);
+        fheuint.encrypt_sk(module, k_value, &sk_prep, &mut Source::new([61u8; 32]), &mut Source::new([62u8; 32]), scratch.borrow());   // conversion.rs:160-168
+        out.put("fheuint_value", &[1], &[k_value as i64]);
+        out.put("fheuint_raw", &[fheuint.raw_len()], fheuint.raw());                          // ADAPT: every limb of every block, in memory order
+        out.put("fheuint_infos", &[6], &[fheuint.n() as i64, fheuint.base2k() as i64, fheuint.k() as i64, fheuint.dnum() as i64,
+                                         fheuint.rank() as i64, fheuint.blocks() as i64]);    // ADAPT: whatever the type exposes
+        let mut derived: Address<Vec<u8>> = Address::alloc_from_params(&params);
+        derived.set_from_fheuint(module, &fheuint, scratch.borrow());                         // conversion.rs:68-82
+        let d0: &GGSW<Vec<u8>> = &derived.coordinates[0].value[0];
+        out.put("fheuint_digit0", &[raw_ggsw(d0).len()], raw_ggsw(d0));
+    }
+
     // ---- whole flow (needs the SubRam::data accessor patch, see header) ------------------------------------------------
     #[cfg(feature = "kat_rows")]
     {
