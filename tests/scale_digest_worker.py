@@ -35,6 +35,7 @@ def main():
     import make_golden
     from _pkg import load_package
     d = json.load(open(os.path.join(ROOT, "tests", "golden", "digests_n4096.json")))[str(1 << a.log_max_addr)]
+    d.setdefault("max_addr", 1 << a.log_max_addr)
     d.setdefault("params", {})
     inp = make_golden.inputs(po.OParams(max_addr=d["max_addr"], word_size=d["word_size"], **d["params"]), d["seed"])
     assert {k: sha(v) for k, v in inp.items()} == d["inputs"], "setup side not reproducible on this machine"
@@ -77,6 +78,7 @@ def main():
     r = ram.read(addr, keys)
     q = ram.read_prepare_write(addr, keys)
     rows_rpw = engine.store_encrypted()
+    tree_rpw = engine.tree(0) if rank == 0 else None
     ram.write(inp["w"] if rank == 0 else None, addr, keys)
     rows_w = engine.store_encrypted()
     rb = ram.read(addr, keys)
@@ -94,7 +96,7 @@ def main():
     f_rpw, f_w = whole(rows_rpw), whole(rows_w)
     rc = 0
     if rank == 0:
-        out = {"read": sha(r), "rpw": sha(q), "rows_after_rpw": sha(f_rpw), "tree_after_rpw": sha(engine.tree(0)),
+        out = {"read": sha(r), "rpw": sha(q), "rows_after_rpw": sha(f_rpw), "tree_after_rpw": sha(tree_rpw),
                "rows_after_write": sha(f_w), "readback": sha(rb)}
         ok = out == want
         print(json.dumps({"mode": "ranks", "backend": a.dist_backend, "n": world, "log_max_addr": a.log_max_addr, "digests_ok": ok,
