@@ -123,6 +123,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* cy = getenv("FHERAM_CHAIN_Y");
         c->chain_y = cy ? (cy[0] == '0' ? 0 : (cy[0] == '1' ? 1 : 2)) : 2;
+        const char* ez = getenv("FHERAM_EP_Z");
+        c->ep_z = (ez && ez[0] == '1') ? 1 : 0;   // measured slower than the round-3 product chain (61.3 against 56.4 us per product, profiles/r04_chain_ab.txt): off
         const char* gr = getenv("FHERAM_GRAPH");
         c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
         // a captured launch sequence must be a pure function of (context, address, op): under replay the write always
@@ -148,6 +150,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product_fine<3, 4>));
     LDSATTR((&k_ext_product_fine<4, 5>));
     LDSATTR((&k_ext_product_chain<3, 4>));
+    LDSATTR((&k_ext_product_chain_z<4>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3, 1>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3, 2>));

@@ -1294,6 +1294,9 @@ __device__ __forceinline__ void fold_limb(double (&od)[E], double (&ec)[E], cons
 #ifndef FK_Z_SKEW
 #define FK_Z_SKEW 1          // ks_trace_z: the two inverse transforms of a batch half a phase apart (ntt_inv2_skew)
 #endif
+#ifndef FK_Z_EARLY
+#define FK_Z_EARLY 0    // ks_trace_z: the first operands of a column requested ahead of it (in front of the forward transforms / behind the other column's last transforms): measured neutral (37.68 against 37.64 us per step), 8 registers more: off
+#endif
 #ifndef FK_Z_SKEW_ODD
 #define FK_Z_SKEW_ODD 0
 #endif
@@ -1375,7 +1378,7 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
             if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
     };
     constexpr int PF = FK_Z_PREFETCH;   // operand polynomials of the next limb requested BEFORE the transforms (the others behind them)
-    fetch(SK - 1, 1, 0, PF);
+    fetch(SK - 1, 1, 0, FK_Z_EARLY ? SX : PF);   // FK_Z_EARLY: all of them (no column starts with an exposed round trip: 4-5k ticks per column in the stamps)
     YSTAMP(2);
     fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
     YSTAMP(3);
@@ -1410,7 +1413,7 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
         }
 #pragma unroll
         for (int k = 0; k < E; k++) ec[k] = 0.0;
-        fetch(SK - 1, co, PF, SX);   // (the first PF polynomials were requested in front of the forward transforms / of column 1's last transforms)
+        if constexpr (!FK_Z_EARLY) fetch(SK - 1, co, PF, SX);   // (FK_Z_EARLY: requested in front of the forward transforms / behind column 1's last transforms)
         if constexpr ((SK & 1) && FK_Z_BI == 2) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
         // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
         auto batch = [&](auto nb_tag, int j) {
@@ -1453,6 +1456,7 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
             }
             if constexpr (PF < SX) {   // the rest of the next limb's operands: their fetch runs under the fold and the first products
                 if (j >= NB) fetch(j - NB, co, PF, SX);
+                else if (FK_Z_EARLY && ci == 0) fetch(SK - 1, 0, PF, SX);   // column 0's first operands: under column 1's window and stores
             }
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         };
@@ -1510,8 +1514,10 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
             }
-            if constexpr (PF < SX) {   // the rest of the next limb's operands: their fetch runs under the fold and the first products
+            if constexpr (PF < SX) {   // the next limb's operands: their fetch runs under the first products (requested in FRONT of the fold, the compiler
+                                       // does not come back: clang 22 of ROCm 7.2 loops forever on that variant)
                 if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, PF, SX);
+                else if (FK_Z_EARLY && ci == 0) fetch(SK - 1, 0, PF, SX);   // column 0's first operands: under column 1's window and stores
             }
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         }
@@ -1544,6 +1550,9 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
 // the same): the consumer takes its three digits from A in FP64 (no int32 limbs, no conversions between steps).
 //   IN_A  : the input is in that form (else an int32 GLWE)       OUT_A : the output is written in that form
 // ---------------------------------------------------------------------------------------
+#ifndef FK_EPZ_G
+#define FK_EPZ_G 2
+#endif
 #ifndef FK_EPZ_PARK
 #define FK_EPZ_PARK 1
 #endif
@@ -1606,91 +1615,76 @@ __device__ __forceinline__ void ep_run_z(GlweRef a, GlweRef res, const double* _
 #pragma unroll
         for (int k = 0; k < E; k++) park[64 * k] = x1[SA - 1][k];
     }
-    auto mac_x1 = [&](double (&acc_)[E], int r) {
+    auto mac_x1 = [&](double (&acc_)[E], int r, const OpRegs& gg) {
         if (FK_EPZ_PARK && r == SA - 1) {
             double xp[E];
 #pragma unroll
             for (int k = 0; k < E; k++) xp[k] = park[64 * k];
-            mac_regs(acc_, xp, g[r]);
-        } else mac_regs(acc_, x1[r], g[r]);
+            mac_regs(acc_, xp, gg);
+        } else mac_regs(acc_, x1[r], gg);
     };
 
     // operand polynomial (cin, r) of output limb j, column co
     auto opnd = [&](int cin, int r, int j, int co) { return ggsw + (long)(((2 * r + cin) * SG + j) * 2 + co) * N; };
+    static_assert(SG == 4, "two pairs of output limbs per column");
+    // the first pair's contribution to V waits in a slot nobody else reads (the step's output slot while the output is in the
+    // A form: the thread's own final store goes to the very same address; the input slot — dead behind the forward
+    // transforms' barriers, and never the chain's source since n >= 2 — when the step writes int32 limbs): no accumulator
+    // is live across the second pair's transforms
+    double* t1p = OUT_A ? reinterpret_cast<double*>(rp) : const_cast<double*>(reinterpret_cast<const double*>(ap));
+    constexpr int NG = FK_EPZ_G;   // operand register sets in the ring (2 or 3)
+    // the 12 operand polynomials of a pair of limbs in product order; polynomial q uses set q % NG and is requested NG places ahead
+    auto opq = [&](int q, int jp, int co) { return opnd((q / SA) & 1, q % SA, jp - q / (2 * SA), co); };
 #if FK_EPZ_UNROLL_COLS
 #pragma unroll
 #else
 #pragma unroll 1
 #endif
     for (int co = 0; co < 2; co++) {
-        double od[E], ec[E];
 #pragma unroll
-        for (int k = 0; k < E; k++) { od[k] = 0.0; ec[k] = 0.0; }
-#pragma unroll
-        for (int r = 0; r < SA; r++) load_ops(g[r], opnd(0, r, SG - 1, co), tid);
-#pragma unroll 1
-        for (int j = SG - 1; j >= 0; j -= 2) {
-            const bool two = j >= 1;
+        for (int pr = 0; pr < 2; pr++) {
+            const int jp = SG - 1 - 2 * pr;      // the pair (jp, jp - 1)
             double acc[2][E];
 #pragma unroll
             for (int k = 0; k < E; k++) { acc[0][k] = 0.0; acc[1][k] = 0.0; }
-            // 12 operand polynomials per pair of limbs through three register sets: each set is refilled with the polynomial
-            // three places further on as soon as its product has been taken
 #pragma unroll
-            for (int r = 0; r < SA; r++) {
-                mac_regs(acc[0], x0[r], g[r]);
+            for (int q = 0; q < NG; q++) load_ops(g[q], opq(q, jp, co), tid);
+#pragma unroll
+            for (int q = 0; q < 4 * SA; q++) {
+                const int b = q / (2 * SA), cin = (q / SA) & 1, r = q % SA;
+                if (cin == 0) mac_regs(acc[b], x0[r], g[q % NG]); else mac_x1(acc[b], r, g[q % NG]);
                 __builtin_amdgcn_sched_barrier(0);
-                load_ops(g[r], opnd(1, r, j, co), tid);
+                if (q + NG < 4 * SA) load_ops(g[q % NG], opq(q + NG, jp, co), tid);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            YSTAMP(8 + (co * SG + 2 * pr) * 4);
+            if constexpr (FK_EPZ_SKEW) ntt_inv2_skew<true, true>(acc, tw, data, data + LDS_DATA, tid);
+            else ntt_inv<2, true, true>(acc, tw, data, tid);
+            YSTAMP(9 + (co * SG + 2 * pr) * 4);
+            if (pr == 0) {      // limbs 3, 2:  e + big_2
 #pragma unroll
-            for (int r = 0; r < SA; r++) {
-                mac_x1(acc[0], r);
-                __builtin_amdgcn_sched_barrier(0);
-                if (two) load_ops(g[r], opnd(0, r, j - 1, co), tid);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (two) {
+                for (int k = 0; k < E; k++) gstore_f64(t1p + (long)co * N, (unsigned)(tid + T * k) * 8u, carry_of(acc[0][k]) + acc[1][k]);
+            } else {            // limbs 1, 0, the first pair's part, window, output
+                double t1[E];
 #pragma unroll
-                for (int r = 0; r < SA; r++) {
-                    mac_regs(acc[1], x0[r], g[r]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_ops(g[r], opnd(1, r, j - 1, co), tid);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < E; k++) t1[k] = gload_f64(t1p + (long)co * N, (unsigned)(tid + T * k) * 8u);
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    double v = __builtin_fma(cmod34(acc[0][k]), TWO_B, t1[k]);
+                    v = __builtin_fma(cmod17(acc[1][k]), TWO_2B, v);
+                    double a_ = window51(v);
+                    if constexpr (OUT_A) {
+                        gstore_f64(reinterpret_cast<double*>(rp) + (long)co * N, (unsigned)(tid + T * k) * 8u, a_);
+                    } else {
+                        const double d2 = take_digit(a_);
+                        const double d1 = take_digit(a_);
+                        gstore_i32(rp + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
+                        gstore_i32(rp + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
+                        gstore_i32(rp + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
+                    }
                 }
-#pragma unroll
-                for (int r = 0; r < SA; r++) mac_x1(acc[1], r);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            YSTAMP(8 + (co * SG + (SG - 1 - j)) * 4);
-            if (two) {
-                if constexpr (FK_EPZ_SKEW) ntt_inv2_skew<true, true>(acc, tw, data, data + LDS_DATA, tid);
-                else ntt_inv<2, true, true>(acc, tw, data, tid);
-                YSTAMP(9 + (co * SG + (SG - 1 - j)) * 4);
-                if (j >= 2) {
-#pragma unroll
-                    for (int r = 0; r < SA; r++) load_ops(g[r], opnd(0, r, j - 2, co), tid);
-                }
-                fold_limb<SG>(od, ec, acc[0], j);
-                fold_limb<SG>(od, ec, acc[1], j - 1);
-            } else {
-                ntt_inv<1, true, true>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
-                fold_limb<SG>(od, ec, acc[0], j);
-            }
-            YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < E; k++) {
-            double a_ = window51(od[k]);
-            if constexpr (OUT_A) {
-                gstore_f64(reinterpret_cast<double*>(rp) + (long)co * N, (unsigned)(tid + T * k) * 8u, a_);
-            } else {
-                const double d2 = take_digit(a_);
-                const double d1 = take_digit(a_);
-                gstore_i32(rp + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
-                gstore_i32(rp + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
-                gstore_i32(rp + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
-            }
+            YSTAMP(10 + (co * SG + 2 * pr) * 4);
         }
     }
     YSTAMP(5);
