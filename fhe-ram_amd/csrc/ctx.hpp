@@ -99,7 +99,7 @@ struct fheram_ctx {
     double* d_big2 = nullptr;      // same, for launches on the side stream
     int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel paths
     int chain = 1;                 // FHERAM_CHAIN=0: one launch per step instead of one launch per dependent chain of fused steps
-    int chain_y = 2;               // FHERAM_CHAIN_Y=0: the intermediates of a trace chain as int32 limbs; 1: as Y = ceil(A/2) with the limb-by-limb normalisation (ks_trace_y, round 3); 2: Y with the closed-form normalisation (ks_trace_z)
+    int chain_y = 3;               // FHERAM_CHAIN_Y=0: the intermediates of a trace chain as int32 limbs; 1: as Y = ceil(A/2) with the limb-by-limb normalisation (ks_trace_y, round 3); 2: Y with the closed-form normalisation (ks_trace_z); 3: the same, handed over through LDS and registers (ks_trace_l)
     int fine_split = 1;            // FHERAM_FINE_SPLIT=0 disables the fine limb split (one workgroup per input and output limb)
     int use_graph = 0;             // FHERAM_GRAPH=1: replay each op's launch sequence from a hipGraph (per address)
     int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo

@@ -1541,6 +1541,256 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
 }
 
 // ---------------------------------------------------------------------------------------
+// ks_trace_l (round 4): ks_trace_z with the hand-over between the steps of a chain through LDS and registers.  Producer and
+// consumer of an intermediate ciphertext are the same workgroup; what the consumer needs of it is (i) the mask column's Y in
+// natural order somewhere every wave can gather from (its digits, seen through phi_g, are the inputs of the forward
+// transforms), (ii) each thread's own coefficients of both columns (the accumulators start from them), (iii) the body
+// column's Y in natural order for ONE gather (phi_g of the body, added to the body column's accumulator).  So: column 1's
+// output goes to exchange buffer 2 once the body column's gather of this step has been taken from there (one barrier), the
+// body column's output stays in registers (vc) and is staged into buffer 2 by the NEXT step behind the first fence of its
+// inverse transforms.  No global loads or stores between the steps (round 3's register hand-over kept the global round trip
+// of the gathers' staging; here it is gone), no store drain at a step's end, and one workgroup barrier fewer per step.
+//   IN_Y  : the input comes that way (else: an int32 GLWE, first step)    OUT_Y : the output leaves that way (else int32, last step)
+// ---------------------------------------------------------------------------------------
+template <int SK, bool IN_Y, bool OUT_Y>
+__device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool load_tw, const int tid, double (&vc)[E], const bool stamp_on = false) {
+    YSTAMP(0);
+    constexpr int SX = 3;
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    TwRegs twr;
+    if (load_tw) twiddles_issue(twr, ka.tw, tid);
+    const int32_t* ap = at(ka.a);
+    int32_t* op = at(ka.out);
+    const int sidx0 = (tid * ka.ginv) & (2 * N - 1);      // phi_g: destination i' = tid + T*k takes +-source i = i' * ginv mod 2N
+    const int sstep = (T * ka.ginv) & (2 * N - 1);
+
+    auto y_of = [](const RawX<KS_TRACE, SX>& r) {
+        double a_ = __builtin_fma(__builtin_fma((double)r.a[0], TWO_B, (double)r.a[1]), TWO_B, (double)r.a[2]);
+        a_ = r.neg ? -a_ : a_;                                       // the rotation's sign comes before the shift
+        return __builtin_floor(__builtin_fma(a_, 0.5, 0.5));        // ceil(A / 2)
+    };
+    auto load_column = [&](int col, double (&y)[E]) {
+        if constexpr (IN_Y) {
+            const double* yp = reinterpret_cast<const double*>(ap);
+#pragma unroll
+            for (int k = 0; k < E; k++) y[k] = gload_f64(yp + (long)col * N, (unsigned)(tid + T * k) * 8u);
+        } else {
+            RawX<KS_TRACE, SX> rw[E];
+#pragma unroll
+            for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, col, tid + T * k, rw[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < E; k++) y[k] = y_of(rw[k]);
+        }
+    };
+    // V of both columns starts as the column's own Y (natural order).  Hand-over through LDS and registers (IN_Y): the mask
+    // column's Y was staged in exchange buffer 2 by the previous step (published by that step's later barriers), the body
+    // column's Y comes in registers (vc).  First step of a chain: both from the int32 source.
+    double* stage2 = data + 2 * LDS_DATA;
+    double v1[E], v0[E];
+    if constexpr (IN_Y) {
+#pragma unroll
+        for (int k = 0; k < E; k++) { v0[k] = vc[k]; v1[k] = stage2[tid + T * k]; }
+    } else {
+        load_column(1, v1);
+        load_column(0, v0);
+#pragma unroll
+        for (int k = 0; k < E; k++) stage2[tid + T * k] = v1[k];
+        if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();   // its barrier also publishes the staged column
+    }
+    YSTAMP(1);
+    // the digits of the mask column seen through phi_g (to be transformed)
+    double xh[SX][E];
+    {
+        int sidx = sidx0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const bool ng = sidx >= N;
+            double c = stage2[sidx & (N - 1)];
+            const double d2 = take_digit(c);
+            const double d1 = take_digit(c);
+            xh[2][k] = ng ? -d2 : d2;
+            xh[1][k] = ng ? -d1 : d1;
+            xh[0][k] = ng ? -c : c;
+            sidx = (sidx + sstep) & (2 * N - 1);
+        }
+    }
+    // operands of the first output limb of column 1: in flight during the forward transforms
+    OpRegs g[SX];
+    auto fetch = [&](int j, int co, int r0, int r1) {
+#pragma unroll
+        for (int r = 0; r < SX; r++)
+            if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
+    };
+    constexpr int PF = FK_Z_PREFETCH;   // operand polynomials of the next limb requested BEFORE the transforms (the others behind them)
+    fetch(SK - 1, 1, 0, FK_Z_EARLY ? SX : PF);   // FK_Z_EARLY: all of them (no column starts with an exposed round trip: 4-5k ticks per column in the stamps)
+    YSTAMP(2);
+    fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
+    YSTAMP(3);
+    // the body column's Y goes to buffer 2 (natural order), for the gather of column 0 (own coefficient +- phi_g's source
+    // coefficient), once every wave is through the forward transforms (their wave-local exchanges use that buffer too)
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < E; k++) stage2[tid + T * k] = v0[k];
+    double y1n[E];   // column 1's output Y, on its way to buffer 2 (the next step's mask staging)
+#pragma unroll
+    for (int k = 0; k < E; k++) y1n[k] = 0.0;
+#if FK_Z_UNROLL_COLS
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+    for (int ci = 0; ci < 2; ci++) {
+        const int co = 1 - ci;
+        double od[E], ec[E];
+        if (co == 1) {
+#pragma unroll
+            for (int k = 0; k < E; k++) od[k] = v1[k];
+        } else {
+            int sidx = sidx0;
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const double b = stage2[sidx & (N - 1)];
+                od[k] = stage2[tid + T * k] + ((sidx >= N) ? -b : b);      // Y_body + phi_g(Y_body)
+                sidx = (sidx + sstep) & (2 * N - 1);
+            }
+            if constexpr (OUT_Y) {      // every wave has gathered: buffer 2 takes the next step's mask column
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < E; k++) stage2[tid + T * k] = y1n[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) ec[k] = 0.0;
+        if constexpr (!FK_Z_EARLY) fetch(SK - 1, co, PF, SX);   // (FK_Z_EARLY: requested in front of the forward transforms / behind column 1's last transforms)
+        if constexpr ((SK & 1) && FK_Z_BI == 2) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
+        // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
+        auto batch = [&](auto nb_tag, int j) {
+            constexpr int NB = decltype(nb_tag)::value;
+            double acc[NB][E];
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
+            // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
+#pragma unroll
+            for (int r = 0; r < SX; r++) {
+                mac_regs(acc[0], xh[r], g[r]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NB == 2) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (NB == 2) {
+#pragma unroll
+                for (int r = 0; r < SX; r++) mac_regs(acc[NB - 1], xh[r], g[r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next limbs' first operands (or the next column's): requested HERE, their fetch runs under the transforms
+            if constexpr (PF > 0) {
+                if (j >= NB) fetch(j - NB, co, 0, PF);
+                else if (ci == 0) fetch(SK - 1, 0, 0, PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
+            if constexpr (NB == 2) {
+                if constexpr (FK_Z_SKEW_ODD) ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);   // (5-limb keys: six spilled registers with the skewed pair, none without)
+                else ntt_inv<2, true, false>(acc, tw, data, tid);
+                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+                fold_limb<SK>(od, ec, acc[0], j);
+                fold_limb<SK>(od, ec, acc[NB - 1], j - 1);
+            } else {
+                ntt_inv<1, true, false>(acc, tw, data, tid);
+                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+                fold_limb<SK>(od, ec, acc[0], j);
+            }
+            if constexpr (PF < SX) {   // the rest of the next limb's operands: their fetch runs under the fold and the first products
+                if (j >= NB) fetch(j - NB, co, PF, SX);
+                else if (FK_Z_EARLY && ci == 0) fetch(SK - 1, 0, PF, SX);   // column 0's first operands: under column 1's window and stores
+            }
+            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
+        };
+        if constexpr (FK_Z_BI == 2) {
+#if FK_Z_UNROLL_PAIRS
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+            for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
+            if constexpr (SK & 1) batch(std::integral_constant<int, 1>{}, 0);
+        } else {
+#pragma unroll 1
+            for (int j = SK - 1; j >= 0; j--) batch(std::integral_constant<int, 1>{}, j);
+        }
+        } else {
+#pragma unroll 1
+        for (int j = SK - 1; j >= 0; j -= FK_Z_BI) {
+            const bool two = FK_Z_BI == 2 && j >= 1;
+            double acc[FK_Z_BI][E];
+#pragma unroll
+            for (int b = 0; b < FK_Z_BI; b++)
+#pragma unroll
+                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
+            // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
+#pragma unroll
+            for (int r = 0; r < SX; r++) {
+                mac_regs(acc[0], xh[r], g[r]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (two) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (FK_Z_BI == 2) {
+                if (two) {
+#pragma unroll
+                    for (int r = 0; r < SX; r++) mac_regs(acc[FK_Z_BI - 1], xh[r], g[r]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next limbs' first operands (or the next column's): requested HERE, their fetch runs under the transforms
+            if constexpr (PF > 0) {
+                if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, 0, PF);
+                else if (ci == 0) fetch(SK - 1, 0, 0, PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
+            if (two) {
+                if constexpr (FK_Z_SKEW && FK_Z_BI == 2) ntt_inv2_skew<true, false>(*reinterpret_cast<double(*)[2][E]>(&acc[0]), tw, data, data + LDS_DATA, tid);
+                else ntt_inv<FK_Z_BI, true, false>(acc, tw, data, tid);
+                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+                fold_limb<SK>(od, ec, acc[0], j);
+                fold_limb<SK>(od, ec, acc[FK_Z_BI - 1], j - 1);
+            } else {
+                ntt_inv<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
+                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+                fold_limb<SK>(od, ec, acc[0], j);
+            }
+            if constexpr (PF < SX) {   // the next limb's operands: their fetch runs under the first products (requested in FRONT of the fold, the compiler
+                                       // does not come back: clang 22 of ROCm 7.2 loops forever on that variant)
+                if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, PF, SX);
+                else if (FK_Z_EARLY && ci == 0) fetch(SK - 1, 0, PF, SX);   // column 0's first operands: under column 1's window and stores
+            }
+            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
+        }
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            double a_ = window51(od[k]);
+            if constexpr (OUT_Y) {
+                const double yn = __builtin_floor(__builtin_fma(a_, 0.5, 0.5));
+                if (co == 1) y1n[k] = yn; else vc[k] = yn;      // nothing goes to global memory between the steps of a chain
+            } else {
+                const double d2 = take_digit(a_);
+                const double d1 = take_digit(a_);
+                gstore_i32(op + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
+                gstore_i32(op + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
+                gstore_i32(op + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
+            }
+        }
+    }
+    YSTAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------
 // ep_run_z (round 4): the external product of a product chain with the normalisation in closed form (see ks_trace_z):
 // res = normalize_{4 -> 3 limbs}(sum_j big_j) is the balanced digit vector of
 //        V = carry(big_3) + big_2 + cmod(big_1, 2^34) * 2^17 + cmod(big_0, 2^17) * 2^34      modulo 2^51,
@@ -1741,7 +1991,7 @@ struct KsChainArgs {
 // file, and ANY other wave resident on the CU — the one-wave gate launch that read_prepare_write parks on the side stream is
 // enough — keeps the workgroup off that CU: a 256-workgroup launch on 256 CUs then runs in two rounds (+0.24 ms per
 // read_prepare_write, measured when the Y-form kernel first compiled to 250).  Capped so that a small wave still fits.
-template <int SX, int SK, int SO, int YF = 0>   // YF: 0 limbs, 1 Y form (ks_trace_y), 2 Y form with the closed-form normalisation (ks_trace_z)
+template <int SX, int SK, int SO, int YF = 0>   // YF: 0 limbs, 1 Y form (ks_trace_y), 2 Y form with the closed-form normalisation (ks_trace_z), 3 the same handed over through LDS and registers (ks_trace_l)
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.pred) {
@@ -1759,6 +2009,9 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         }
     }
     KsArgs ka = ca.base;
+    [[maybe_unused]] double vcarry[E];   // YF = 3: the body column's Y on its way from one step to the next
+#pragma unroll
+    for (int k = 0; k < E; k++) vcarry[k] = 0.0;
 #pragma unroll 1
     for (int i = 0; i < ca.n; i++) {
         ka.out = ca.buf[i & 1];
@@ -1768,7 +2021,12 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
         __builtin_assume(tid >= 0 && tid < T);
-        if constexpr (YF == 2) {
+        if constexpr (YF == 3) {
+            static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
+            if (i == 0) ks_trace_l<SK, false, true>(ka, lds, true, tid, vcarry);
+            else if (i + 1 < ca.n) ks_trace_l<SK, true, true>(ka, lds, false, tid, vcarry, YSTAMP_STEP(i));
+            else ks_trace_l<SK, true, false>(ka, lds, false, tid, vcarry);
+        } else if constexpr (YF == 2) {
             static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
             if (i == 0) ks_trace_z<SK, false, true>(ka, lds, true, tid);
             else if (i + 1 < ca.n) ks_trace_z<SK, true, true>(ka, lds, false, tid, YSTAMP_STEP(i));
@@ -1781,7 +2039,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         } else {
             ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
         }
-        __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
+        if constexpr (YF != 3) __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over (YF = 3: nothing passes through global memory)
         ka.a = ka.out;
         ka.rot_mul = 0;
         ka.rot_base = 0;

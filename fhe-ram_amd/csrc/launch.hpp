@@ -242,13 +242,15 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
     for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
-    const int yf = n >= 2 ? c->chain_y : 0;   // intermediates handed over as Y = ceil(A/2): 1 ks_trace_y, 2 ks_trace_z (closed-form normalisation)
+    const int yf = n >= 2 ? c->chain_y : 0;   // intermediates handed over as Y = ceil(A/2): 1 ks_trace_y, 2 ks_trace_z (closed-form normalisation), 3 ks_trace_l (the same through LDS and registers)
     if (c->s_evk == 5) {
-        if (yf == 2) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf == 3) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        else if (yf == 2) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 1>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     } else {
-        if (yf == 2) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf == 3) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        else if (yf == 2) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 1>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }

@@ -10,11 +10,11 @@ from _pkg import load_package
 pkg = load_package()
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-forms = [f for f in os.environ.get("AB_FORMS", "2,1").split(",")]   # "2": the round-4 forms (ks_trace_z, ep_run_z); "1": round 3's
+forms = [f for f in os.environ.get("AB_FORMS", "3,2,1").split(",")]   # "2": the round-4 forms (ks_trace_z, ep_run_z); "1": round 3's
 rams = {}
 for f in forms:
     os.environ["FHERAM_CHAIN_Y"] = f
-    os.environ["FHERAM_EP_Z"] = "1" if f == "2" else "0"
+    os.environ["FHERAM_EP_Z"] = "0"
     rams[f] = pkg.Ram.new_from_ram_params(4, [3, 3, 3, 3], 1 << 12)
 cases = ((0, "trace chain", 12), (0, "trace chain", 6), (1, "product chain", 4))
 res = {(f, c): [] for f in forms for c in cases}
