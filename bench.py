@@ -600,10 +600,11 @@ def main():
             # PRIMARY roofline = the roof that binds this kernel: the FP64 vector ALU.  Every FP64 VALU instruction
             # (mul / add / fma / rndne: all issue at the FMA rate) is priced as one FMA slot = 2 FLOP, so that achieved
             # and peak are in the guide's TFLOP/s; frac = instruction rate / 39.3 T instr/s.
-            form = int(os.environ.get("FHERAM_CHAIN_Y", "2")[:1] or 2)
+            form = min(int(os.environ.get("FHERAM_CHAIN_Y", "3")[:1] or 3), 3)
             fname = {0: "ks_run<KS_TRACE,3,%d,3,NCO=2> (int32 limbs between steps)", 1: "ks_trace_y<%d> (Y form, limb-by-limb normalisation)",
-                     2: "ks_trace_z<%d> (Y form, closed-form normalisation, paired inverse transforms)"}[min(form, 2)] % s_evk
-            out["roofline"] = {"kernel": f"fused trace step {fname} inside k_keyswitch_chain<3,{s_evk},3,{min(form, 2)}>, one workgroup per ciphertext",
+                     2: "ks_trace_z<%d> (Y form, closed-form normalisation, paired inverse transforms)",
+                     3: "ks_trace_l<%d> (closed-form normalisation, paired inverse transforms, steps handed over through LDS and registers)"}[form] % s_evk
+            out["roofline"] = {"kernel": f"fused trace step {fname} inside k_keyswitch_chain<3,{s_evk},3,{form}>, one workgroup per ciphertext",
                                "bound": "valu_fp64", "achieved": 2 * ach, "peak": 2 * FP64_VALU_PEAK_TINSTR, "unit": "TFLOP/s",
                                "frac": ach / FP64_VALU_PEAK_TINSTR,
                                "achieved_T_fp64_instr_s": ach, "peak_T_fp64_instr_s": FP64_VALU_PEAK_TINSTR,
@@ -619,7 +620,7 @@ def main():
                                                  f"that is otherwise uninstrumented ({light['elapsed'] * 1e3 / args.steps:.3f} ms per step against "
                                                  f"{ms_per_step:.3f} in the timed region)") if lightly else "HIP events around every launch (all-classes pass)",
                                "launch_unit": "one trace step over the batch (a chain launch runs 6 or 12 of them: HIP-event time of the launch / its steps)",
-                               "chain_launch": ({"kernel": f"k_keyswitch_chain<3,{s_evk},3,{min(form, 2)}>", "launches": chain["launches"],
+                               "chain_launch": ({"kernel": f"k_keyswitch_chain<3,{s_evk},3,{form}>", "launches": chain["launches"],
                                                  "avg_launch_ms": (light["chain"]["ms"] if lightly else chain["ms"]) / chain["launches"],
                                                  "avg_steps_per_launch": chain["blocks"] / chain["launches"] / blocks}
                                                 if chain["launches"] else None),

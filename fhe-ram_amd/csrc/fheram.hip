@@ -123,6 +123,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* cy = getenv("FHERAM_CHAIN_Y");
         c->chain_y = cy ? (cy[0] == '0' ? 0 : (cy[0] == '1' ? 1 : (cy[0] == '2' ? 2 : 3))) : 3;
+        const char* er = getenv("FHERAM_EP_R");
+        c->ep_r = (er && er[0] == '0') ? 0 : 1;
         const char* ez = getenv("FHERAM_EP_Z");
         c->ep_z = (ez && ez[0] == '1') ? 1 : 0;   // measured slower than the round-3 product chain (61.3 against 56.4 us per product, profiles/r04_chain_ab.txt): off
         const char* gr = getenv("FHERAM_GRAPH");
@@ -151,6 +153,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product_fine<4, 5>));
     LDSATTR((&k_ext_product_chain<3, 4>));
     LDSATTR((&k_ext_product_chain_z<4>));
+    LDSATTR((&k_ext_product_chain_r<4>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3, 1>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3, 2>));

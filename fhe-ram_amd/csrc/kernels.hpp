@@ -1791,6 +1791,130 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
 }
 
 // ---------------------------------------------------------------------------------------
+// ep_step_r (round 4): one product INSIDE a product chain, handing its result to the next product of the same workgroup in
+// registers and LDS instead of through global memory.  A product's input is consumed at the natural coefficients of each
+// thread only (no gather: the external product has no automorphism), so the hand-over needs no barrier at all: the result
+// travels as A = the integer whose balanced base-2^17 digits are the three output limbs (closed-form normalisation, see
+// ks_trace_z: one accumulator per coefficient, no carry chain), column 1 in registers (ac), column 0 — finished first — in
+// this wave's own region of the third exchange buffer, which the inverse transforms leave alone.  The consumer takes its digits
+// with take_digit.  Same streaming structure as ep_run (operands of the next limb requested around the normalisation step).
+//   IN_R : the input comes that way (else an int32 GLWE: first product)     OUT_R : the output leaves that way (else int32: last)
+// ---------------------------------------------------------------------------------------
+template <int SG, bool IN_R, bool OUT_R>
+__device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* __restrict__ ggsw, const double* __restrict__ tw_g,
+                                          double* lds, bool load_tw, const int tid, double (&ac)[E], const bool stamp_on = false) {
+    YSTAMP(0);
+    constexpr int SA = 3;
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    TwRegs twr;
+    if (load_tw) twiddles_issue(twr, tw_g, tid);
+    const int32_t* ap = at(a);
+    int32_t* rp = at(res);
+    double* park = data + 2 * LDS_DATA + (tid >> 6) * (64 * (E + 1)) + (tid & 63);   // this wave's own region of buffer 2
+    double x0[SA][E], x1[SA][E];
+    auto digits_of = [&](const double (&av)[E], double (&x)[SA][E]) {
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            double c = av[k];
+            x[2][k] = take_digit(c);
+            x[1][k] = take_digit(c);
+            x[0][k] = c;            // A lies in the digit window: the second quotient IS the top digit
+        }
+    };
+    auto load_limbs = [&](int col, double (&x)[SA][E]) {
+        int xi[SA][E];
+#pragma unroll
+        for (int r = 0; r < SA; r++)
+#pragma unroll
+            for (int k = 0; k < E; k++) xi[r][k] = gload_i32(ap + glwe_off(r, col), (unsigned)(tid + T * k) * 4u);
+#pragma unroll
+        for (int r = 0; r < SA; r++)
+#pragma unroll
+            for (int k = 0; k < E; k++) x[r][k] = (double)xi[r][k];
+    };
+    if constexpr (IN_R) {
+        double a0[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) a0[k] = park[64 * k];      // read before the forward transforms overwrite the buffer
+        digits_of(a0, x0);
+    } else {
+        load_limbs(0, x0);
+        if (load_tw) twiddles_commit(twr, tw, tid);
+    }
+    YSTAMP(1);
+    fwd_all<SA>(x0, tw, data, tid);
+    YSTAMP(2);
+    if constexpr (IN_R) digits_of(ac, x1); else load_limbs(1, x1);
+    fwd_all<SA>(x1, tw, data, tid);
+    YSTAMP(3);
+
+    int it = 0;
+#pragma unroll
+    for (int co = 0; co < 2; co++) {   // (unrolled: the carried column is written by the second pass only — a rolled loop keeps its old value alive throughout)
+        double od[E], ec[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) { od[k] = 0.0; ec[k] = 0.0; }
+        OpRegs g[SA];
+#pragma unroll
+        for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co) * N, tid);
+#pragma unroll 1
+        for (int j = SG - 1; j >= 0; j--) {
+            double acc[1][E];
+#pragma unroll
+            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+            ep_mac<SA, SG>(acc[0], x0, x1, g, ggsw, j, co, j - 1, tid);
+            YSTAMP(8 + (co * SG + (SG - 1 - j)) * 4);
+            ntt_inv<1, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);   // double-buffered exchanges: no fence
+            YSTAMP(9 + (co * SG + (SG - 1 - j)) * 4);
+            const bool more = j >= 1;
+            auto fetch1 = [&](int r) { if (more) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (j - 1)) * 2 + co) * N, tid); };
+            fetch1(0);
+            fetch1(1);
+            __builtin_amdgcn_sched_barrier(0);
+            fold_limb<SG>(od, ec, acc[0], j);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch1(2);
+            YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            double a_ = window51(od[k]);
+            if constexpr (OUT_R) {
+                if (co == 0) park[64 * k] = a_; else ac[k] = a_;
+            } else {
+                const double d2 = take_digit(a_);
+                const double d1 = take_digit(a_);
+                gstore_i32(rp + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
+                gstore_i32(rp + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
+                gstore_i32(rp + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
+            }
+        }
+    }
+    YSTAMP(5);
+}
+// the product chain with that hand-over (n >= 2)
+template <int SG>
+__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_ext_product_chain_r(EpChainArgs ca) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    GlweRef in = ca.src;
+    double ac[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) ac[k] = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < ca.n; i++) {
+        const GlweRef out = ca.buf[i & 1];
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));   // see k_ext_product_chain
+        __builtin_assume(tid >= 0 && tid < T);
+        if (i == 0) ep_step_r<SG, false, true>(in, out, ca.ggsw[i], ca.tw, lds, true, tid, ac);
+        else if (i + 1 < ca.n) ep_step_r<SG, true, true>(in, out, ca.ggsw[i], ca.tw, lds, false, tid, ac, YSTAMP_STEP(i + 1));
+        else ep_step_r<SG, true, false>(in, out, ca.ggsw[i], ca.tw, lds, false, tid, ac);
+        in = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // ep_run_z (round 4): the external product of a product chain with the normalisation in closed form (see ks_trace_z):
 // res = normalize_{4 -> 3 limbs}(sum_j big_j) is the balanced digit vector of
 //        V = carry(big_3) + big_2 + cmod(big_1, 2^34) * 2^17 + cmod(big_0, 2^17) * 2^34      modulo 2^51,

@@ -14,7 +14,7 @@ forms = [f for f in os.environ.get("AB_FORMS", "3,2,1").split(",")]   # "2": the
 rams = {}
 for f in forms:
     os.environ["FHERAM_CHAIN_Y"] = f
-    os.environ["FHERAM_EP_Z"] = "0"
+    os.environ["FHERAM_EP_R"] = "1" if f == "3" else "0"
     rams[f] = pkg.Ram.new_from_ram_params(4, [3, 3, 3, 3], 1 << 12)
 cases = ((0, "trace chain", 12), (0, "trace chain", 6), (1, "product chain", 4))
 res = {(f, c): [] for f in forms for c in cases}
