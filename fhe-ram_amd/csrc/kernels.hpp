@@ -1552,8 +1552,12 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
 // of the gathers' staging; here it is gone), no store drain at a step's end, and one workgroup barrier fewer per step.
 //   IN_Y  : the input comes that way (else: an int32 GLWE, first step)    OUT_Y : the output leaves that way (else int32, last step)
 // ---------------------------------------------------------------------------------------
-template <int SK, bool IN_Y, bool OUT_Y>
+//   OUT2: (k_write_chain) the last trace step of write_mid_step hands normalize(ct_hi - trace(ct_hi) + trace(ct_lo X^-row)) (ram.rs:617,625-626)
+//   to write_last_step's products: ka.b = the row (ct_hi), ka.out = trace(ct_hi); the result leaves as A (not Y), the mask column in
+//   buffer 2, the body column in vc (ep_step_r IN = 2)
+template <int SK, bool IN_Y, int OUT>
 __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool load_tw, const int tid, double (&vc)[E], const bool stamp_on = false) {
+    constexpr bool OUT_Y = OUT != 0;
     YSTAMP(0);
     constexpr int SX = 3;
     double* tw = lds;
@@ -1594,6 +1598,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         for (int k = 0; k < E; k++) { v0[k] = vc[k]; v1[k] = stage2[tid + T * k]; }
     } else {
         load_column(1, v1);
+        __builtin_amdgcn_sched_barrier(0);   // (one column's 24 raw limbs at a time)
         load_column(0, v0);
 #pragma unroll
         for (int k = 0; k < E; k++) stage2[tid + T * k] = v1[k];
@@ -1775,7 +1780,19 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
 #pragma unroll
         for (int k = 0; k < E; k++) {
             double a_ = window51(od[k]);
-            if constexpr (OUT_Y) {
+            if constexpr (OUT == 2) {
+                // normalize(ct_hi - trace(ct_hi) + this) in closed form: the three operands as the integers their limbs stand for
+                const int32_t* hp = at(ka.b);
+                const int32_t* tp = op;
+                auto whole = [&](const int32_t* q) {
+                    const double l0 = (double)gload_i32(q + glwe_off(0, co), (unsigned)(tid + T * k) * 4u);
+                    const double l1 = (double)gload_i32(q + glwe_off(1, co), (unsigned)(tid + T * k) * 4u);
+                    const double l2 = (double)gload_i32(q + glwe_off(2, co), (unsigned)(tid + T * k) * 4u);
+                    return __builtin_fma(__builtin_fma(l0, TWO_B, l1), TWO_B, l2);
+                };
+                const double an = window51(whole(hp) - whole(tp) + a_);
+                if (co == 1) y1n[k] = an; else vc[k] = an;
+            } else if constexpr (OUT_Y) {
                 const double yn = __builtin_floor(__builtin_fma(a_, 0.5, 0.5));
                 if (co == 1) y1n[k] = yn; else vc[k] = yn;      // nothing goes to global memory between the steps of a chain
             } else {
@@ -1800,9 +1817,14 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
 // with take_digit.  Same streaming structure as ep_run (operands of the next limb requested around the normalisation step).
 //   IN_R : the input comes that way (else an int32 GLWE: first product)     OUT_R : the output leaves that way (else int32: last)
 // ---------------------------------------------------------------------------------------
-template <int SG, bool IN_R, bool OUT_R>
+//   IN : 0 an int32 GLWE (first product), 1 from the previous product (column 0 parked in LDS, column 1 in ac), 2 from a trace step
+//        (k_write_chain: column 0 in ac, column 1 in exchange buffer 2 in natural order)
+//   OUT: 0 an int32 GLWE (last product), 1 to the next product, 3 to a trace step (k_read_chain: the columns are produced in the
+//        other order and leave as Y = ceil(A/2), the mask column staged in buffer 2, the body column in ac; store_i32: the int32
+//        limbs are stored as well — read_prepare_write's products are in place, ram.rs:502-504)
+template <int SG, int IN, int OUT>
 __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* __restrict__ ggsw, const double* __restrict__ tw_g,
-                                          double* lds, bool load_tw, const int tid, double (&ac)[E], const bool stamp_on = false) {
+                                          double* lds, bool load_tw, const int tid, double (&ac)[E], const bool stamp_on = false, const bool store_i32 = false) {
     YSTAMP(0);
     constexpr int SA = 3;
     double* tw = lds;
@@ -1833,11 +1855,16 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
 #pragma unroll
             for (int k = 0; k < E; k++) x[r][k] = (double)xi[r][k];
     };
-    if constexpr (IN_R) {
+    [[maybe_unused]] double a1s[E];
+    if constexpr (IN == 1) {
         double a0[E];
 #pragma unroll
         for (int k = 0; k < E; k++) a0[k] = park[64 * k];      // read before the forward transforms overwrite the buffer
         digits_of(a0, x0);
+    } else if constexpr (IN == 2) {
+#pragma unroll
+        for (int k = 0; k < E; k++) a1s[k] = data[2 * LDS_DATA + tid + T * k];   // column 1, staged by the trace step (natural order): read before the forward transforms overwrite the buffer
+        digits_of(ac, x0);
     } else {
         load_limbs(0, x0);
         if (load_tw) twiddles_commit(twr, tw, tid);
@@ -1845,13 +1872,14 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
     YSTAMP(1);
     fwd_all<SA>(x0, tw, data, tid);
     YSTAMP(2);
-    if constexpr (IN_R) digits_of(ac, x1); else load_limbs(1, x1);
+    if constexpr (IN == 1) digits_of(ac, x1); else if constexpr (IN == 2) digits_of(a1s, x1); else load_limbs(1, x1);
     fwd_all<SA>(x1, tw, data, tid);
     YSTAMP(3);
 
     int it = 0;
 #pragma unroll
-    for (int co = 0; co < 2; co++) {   // (unrolled: the carried column is written by the second pass only — a rolled loop keeps its old value alive throughout)
+    for (int cc = 0; cc < 2; cc++) {   // (unrolled: the carried column is written by the second pass only — a rolled loop keeps its old value alive throughout)
+        const int co = (OUT == 3) ? 1 - cc : cc;
         double od[E], ec[E];
 #pragma unroll
         for (int k = 0; k < E; k++) { od[k] = 0.0; ec[k] = 0.0; }
@@ -1880,8 +1908,21 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
 #pragma unroll
         for (int k = 0; k < E; k++) {
             double a_ = window51(od[k]);
-            if constexpr (OUT_R) {
+            if constexpr (OUT == 1) {
                 if (co == 0) park[64 * k] = a_; else ac[k] = a_;
+            } else if constexpr (OUT == 3) {
+                // to a trace step: Y = ceil(A / 2); the mask column (first) into buffer 2 in natural order — the inverse transforms
+                // leave that buffer alone, every wave is through the forward transforms, nobody parks in this step, and the barriers
+                // of the other column's transforms publish it —, the body column (last) in registers
+                const double yn = __builtin_floor(__builtin_fma(a_, 0.5, 0.5));
+                if (co == 1) data[2 * LDS_DATA + tid + T * k] = yn; else ac[k] = yn;
+                if (store_i32) {
+                    const double d2 = take_digit(a_);
+                    const double d1 = take_digit(a_);
+                    gstore_i32(rp + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
+                    gstore_i32(rp + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
+                    gstore_i32(rp + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
+                }
             } else {
                 const double d2 = take_digit(a_);
                 const double d1 = take_digit(a_);
@@ -1907,9 +1948,9 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
         __builtin_assume(tid >= 0 && tid < T);
-        if (i == 0) ep_step_r<SG, false, true>(in, out, ca.ggsw[i], ca.tw, lds, true, tid, ac);
-        else if (i + 1 < ca.n) ep_step_r<SG, true, true>(in, out, ca.ggsw[i], ca.tw, lds, false, tid, ac, YSTAMP_STEP(i + 1));
-        else ep_step_r<SG, true, false>(in, out, ca.ggsw[i], ca.tw, lds, false, tid, ac);
+        if (i == 0) ep_step_r<SG, 0, 1>(in, out, ca.ggsw[i], ca.tw, lds, true, tid, ac);
+        else if (i + 1 < ca.n) ep_step_r<SG, 1, 1>(in, out, ca.ggsw[i], ca.tw, lds, false, tid, ac, YSTAMP_STEP(i + 1));
+        else ep_step_r<SG, 1, 0>(in, out, ca.ggsw[i], ca.tw, lds, false, tid, ac);
         in = out;
     }
 }
@@ -2147,9 +2188,9 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         __builtin_assume(tid >= 0 && tid < T);
         if constexpr (YF == 3) {
             static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
-            if (i == 0) ks_trace_l<SK, false, true>(ka, lds, true, tid, vcarry);
-            else if (i + 1 < ca.n) ks_trace_l<SK, true, true>(ka, lds, false, tid, vcarry, YSTAMP_STEP(i));
-            else ks_trace_l<SK, true, false>(ka, lds, false, tid, vcarry);
+            if (i == 0) ks_trace_l<SK, false, 1>(ka, lds, true, tid, vcarry);
+            else if (i + 1 < ca.n) ks_trace_l<SK, true, 1>(ka, lds, false, tid, vcarry, YSTAMP_STEP(i));
+            else ks_trace_l<SK, true, 0>(ka, lds, false, tid, vcarry);
         } else if constexpr (YF == 2) {
             static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
             if (i == 0) ks_trace_z<SK, false, true>(ka, lds, true, tid);
@@ -2167,6 +2208,90 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         ka.a = ka.out;
         ka.rot_mul = 0;
         ka.rot_base = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_read_chain / k_write_chain (round 4): the two dependent chains that a row goes through back to back — one workgroup per
+// ciphertext in both — as ONE launch, the ciphertext handed from the last step of one to the first step of the other in
+// registers and LDS like between the steps of either (ep_step_r, ks_trace_l).
+//   read / read_prepare_write (ram.rs:429-435,502-514): the products of coordinate 0's digits, then the packer levels in which
+//       every row is alone.  store_ep: read_prepare_write's products are in place (ram.rs:502-504): their result is ALSO written
+//       to the rows (ep.buf[(n_ep - 1) & 1]).
+//   write (ram.rs:612-646): write_mid_step's trace(ct_lo X^-row), the elementwise normalize(ct_hi - trace(ct_hi) + that), then
+//       write_last_step's products with the inverse digits of coordinate 0, in place on the rows.
+// What a launch boundary costs between them — the launch gap, the twiddle table, an int32 round trip through L2 with its
+// conversions, the first / last step variants of both chains, and for the write a whole elementwise launch — is paid once.
+// ---------------------------------------------------------------------------------------
+struct RowChainArgs {
+    EpChainArgs ep;
+    KsChainArgs ks;
+    GlweRef hi, trhi;      // k_write_chain: the rows (ct_hi) and trace(ct_hi)
+    int store_ep = 0;      // k_read_chain: the products' result is also stored (in-place products of read_prepare_write)
+};
+template <int SK, int SG>
+__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_read_chain(RowChainArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double vc[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) vc[k] = 0.0;
+    {
+        GlweRef in = ra.ep.src;
+#pragma unroll 1
+        for (int i = 0; i < ra.ep.n; i++) {      // n >= 2
+            const GlweRef out = ra.ep.buf[i & 1];
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));   // see k_ext_product_chain
+            __builtin_assume(tid >= 0 && tid < T);
+            if (i == 0) ep_step_r<SG, 0, 1>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, true, tid, vc);
+            else if (i + 1 < ra.ep.n) ep_step_r<SG, 1, 1>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, false, tid, vc);
+            else ep_step_r<SG, 1, 3>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, false, tid, vc, false, ra.store_ep != 0);
+            in = out;
+        }
+    }
+    KsArgs ka = ra.ks.base;
+#pragma unroll 1
+    for (int i = 0; i < ra.ks.n; i++) {          // n >= 1: every step takes its input from LDS and registers
+        ka.out = ra.ks.buf[i & 1];
+        ka.key = ra.ks.key[i];
+        ka.ginv = ra.ks.ginv[i];
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < T);
+        if (i + 1 < ra.ks.n) ks_trace_l<SK, true, 1>(ka, lds, false, tid, vc);
+        else ks_trace_l<SK, true, 0>(ka, lds, false, tid, vc);
+    }
+}
+template <int SK, int SG>
+__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_write_chain(RowChainArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double vc[E];   // (written by the first step before anything reads it)
+    KsArgs ka = ra.ks.base;
+#pragma unroll 1
+    for (int i = 0; i < ra.ks.n; i++) {          // n >= 2
+        ka.out = ra.ks.buf[i & 1];
+        ka.key = ra.ks.key[i];
+        ka.ginv = ra.ks.ginv[i];
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < T);
+        if (i == 0) ks_trace_l<SK, false, 1>(ka, lds, true, tid, vc);
+        else if (i + 1 < ra.ks.n) ks_trace_l<SK, true, 1>(ka, lds, false, tid, vc);
+        else { ka.b = ra.hi; ka.out = ra.trhi; ks_trace_l<SK, true, 2>(ka, lds, false, tid, vc); }
+        ka.rot_mul = 0;
+        ka.rot_base = 0;
+    }
+    GlweRef in = ra.ep.src;
+#pragma unroll 1
+    for (int i = 0; i < ra.ep.n; i++) {          // n >= 2
+        const GlweRef out = ra.ep.buf[i & 1];
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < T);
+        if (i == 0) ep_step_r<SG, 2, 1>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, false, tid, vc);
+        else if (i + 1 < ra.ep.n) ep_step_r<SG, 1, 1>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, false, tid, vc);
+        else ep_step_r<SG, 1, 0>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, false, tid, vc);
+        in = out;
     }
 }
 

@@ -256,6 +256,47 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }
 }
+// The two chains a row goes through back to back as ONE launch (k_read_chain / k_write_chain): both must be in the fused,
+// one-workgroup-per-ciphertext regime, in the forms that hand over through LDS and registers.
+bool use_row_fuse(const fheram_ctx* c, int d, int n_tr, int gx, int gy) {
+    return c->fuse && c->chain_y == 3 && c->ep_r && d >= 2 && d <= CHAIN_MAX && n_tr >= 2 && n_tr <= CHAIN_MAX &&
+           use_chain(c, d, gx, gy, 4) && !use_mid(c, d, gx, gy, 4, true) && !use_fine_split(c, gx, gy, 2 * 4 * 2 * 3) &&
+           use_chain(c, n_tr, gx, gy, c->s_evk) && !use_mid(c, n_tr, gx, gy, c->s_evk) && !use_fine_split(c, gx, gy, 2 * c->s_evk * 3) &&
+           !(c->use_graph && !c->profile);
+}
+void fill_row_chain(fheram_ctx* c, RowChainArgs& ra, const double* prep, int d, int start, int n_tr) {
+    ra.ep.tw = c->d_tw; ra.ep.n = d;
+    for (int i = 0; i < d; i++) ra.ep.ggsw[i] = prep + (size_t)i * fheram_ctx::GGSW;
+    ra.ks.n = n_tr;
+    for (int i = 0; i < n_tr; i++) { ra.ks.key[i] = trace_key(c, start + i); ra.ks.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
+}
+// read / read_prepare_write: d products of `src` with the prepared digits, then trace steps 0 .. n_tr-1 (the alone packer levels);
+// the result lands in dst; ep_store != nullptr: the products' result is also written there (in-place products of read_prepare_write)
+void launch_read_chain(fheram_ctx* c, GlweRef src, const GlweRef* ep_store, GlweRef dst, const double* prep, int d, int n_tr, int gx, int gy) {
+    ProfScope ps(c, "read_chain_launch", (uint64_t)gx * gy, 1);
+    RowChainArgs ra;
+    fill_row_chain(c, ra, prep, d, 0, n_tr);
+    ra.ep.src = src;
+    ra.ep.buf[0] = ra.ep.buf[1] = ep_store ? *ep_store : dst;     // only the last product stores, and only when asked to
+    ra.store_ep = ep_store ? 1 : 0;
+    ra.ks.base = ks_args(c, dst, dst, dst, trace_key(c, 0), c->gal[0]);
+    ra.ks.buf[0] = ra.ks.buf[1] = dst;                            // only the last step stores
+    ra.hi = dst; ra.trhi = dst;
+    if (c->s_evk == 5) hipLaunchKernelGGL((k_read_chain<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+    else hipLaunchKernelGGL((k_read_chain<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+}
+// write: trace steps 0 .. n_tr-1 of ct_lo * X^-row (src, read rotated), data <- normalize(data - trhi + that), d products in place
+void launch_write_chain(fheram_ctx* c, GlweRef src, int rot_mul, int rot_base, GlweRef data, GlweRef trhi, const double* prep, int d, int n_tr, int gx, int gy) {
+    ProfScope ps(c, "write_chain_launch", (uint64_t)gx * gy, 1);
+    RowChainArgs ra;
+    fill_row_chain(c, ra, prep, d, 0, n_tr);
+    ra.ks.base = ks_args(c, src, src, data, trace_key(c, 0), c->gal[0], 0, rot_mul, rot_base);
+    ra.ks.buf[0] = ra.ks.buf[1] = data;                           // (no trace step stores)
+    ra.hi = data; ra.trhi = trhi;
+    ra.ep.src = data; ra.ep.buf[0] = ra.ep.buf[1] = data;         // only the last product stores: in place on the rows
+    if (c->s_evk == 5) hipLaunchKernelGGL((k_write_chain<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+    else hipLaunchKernelGGL((k_write_chain<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+}
 // The latency-bound end of the path (at most 8 ciphertexts, one per XCD): n trace steps as ONE launch with in-kernel
 // hand-offs (k_trace_tail), followed by the fused chain launch that only runs if that one gave up.
 bool use_tail(const fheram_ctx* c, int n, int gx, int gy) {

@@ -84,6 +84,15 @@ int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweR
         return FHERAM_OK;
     }
     int32_t* leaves;
+    const int L0 = LOGN - ilog2_ceil(c->rows_glob);
+    const bool keep = prepare_write && c->memo && L0 > 0;   // leaves = d_data then: arena A keeps the rows after their alone levels
+    int32_t* packed;
+    if (use_row_fuse(c, d0, L0, R, ws) && !(prepare_write && (d0 & 1))) {
+        // the products and the alone packer levels as ONE launch (k_read_chain): rows after the alone levels in arena A
+        // (read_prepare_write: the products' result also lands in the rows, ram.rs:502-504)
+        launch_read_chain(c, data, prepare_write ? &data : nullptr, A, prep_of(c, 0), d0, L0, R, ws);
+        packed = pack_levels(c, c->d_scrA, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws, 0, L0, keep, c->d_scrC, c->d_scrD);   // ram.rs:435-448 / 510-521: the pairing levels
+    } else {
     if (prepare_write) {
         ep_chain(c, data, data, A, prep_of(c, 0), d0, R, ws);                             // ram.rs:502-504
         leaves = c->d_data;
@@ -91,9 +100,8 @@ int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweR
         ep_chain(c, data, A, B, prep_of(c, 0), d0, R, ws);                                // ram.rs:429-434
         leaves = c->d_scrA;
     }
-    const int L0 = LOGN - ilog2_ceil(c->rows_glob);
-    const bool keep = prepare_write && c->memo && L0 > 0;   // leaves = d_data then: arena A keeps the rows after their alone levels
-    int32_t* packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws, L0, L0, keep, c->d_scrC, c->d_scrD);   // ram.rs:435-448 / 510-521
+    packed = pack_levels(c, leaves, c->d_scrA, c->d_scrB, sy, G, (size_t)R, ws, L0, L0, keep, c->d_scrC, c->d_scrD);   // ram.rs:435-448 / 510-521
+    }
     c->memo_alone = keep ? L0 : 0;
     *packed_out = ref(packed, sy, 0);
     if (to_part) launch_copy(c, *packed_out, part, 1, ws);
@@ -238,6 +246,19 @@ int write_rows(fheram_ctx* c, const fheram_addr* addr) {
     const int ws = c->ws, R = (int)c->rows;
     GlweRef data = ref(c->d_data, sy, G), A = ref(c->d_scrA, sy, G), B = ref(c->d_scrB, sy, G), D = ref(c->d_scrD, sy, G);
     GlweRef trhi = ref(c->d_trhi ? c->d_trhi : c->d_scrA, sy, G);
+    const int d0 = (int)c->base2d[0].size();
+    if (c->n2 == 2 && use_row_fuse(c, d0, LOGN, R, ws)) {
+        // trace(ct_lo * X^-row), normalize(ct_hi - trace(ct_hi) + that) and write_last_step's products as ONE launch (k_write_chain);
+        // it needs trace(ct_hi) and the inverse digits of coordinate 0 from the side stream at its start (that stream's chain holds
+        // every CU until then anyway)
+        hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        launch_write_chain(c, ref(c->d_part, G, 0), c->n_shards, c->shard, data, trhi, prep_inv_of(c, 0), d0, LOGN, R, ws);   // ram.rs:612-646
+        if (c->tree_rotate_pending) {   // root / unsharded: the tree's copy of ct_lo, rotated (see write_top)
+            ProfScope ps(c, "elementwise", ws);
+            hipLaunchKernelGGL((k_rotate<3>), dim3(1, ws, EW_SLICES), dim3(256), 0, c->cur, ref(c->d_part, G, 0), ref(c->d_tree, G, 0), -(int)c->rows_glob);
+            c->tree_rotate_pending = false;
+        }
+    } else {
     if (c->n2 == 2)
         trace_steps(c, ref(c->d_part, G, 0), B, D, 0, LOGN, R, ws, c->n_shards, c->shard);     // tmp_a = trace(ct_lo * X^-row)   ram.rs:621,629
     if (c->tree_rotate_pending) {   // root / unsharded: the tree's copy of ct_lo, rotated (see write_top)
@@ -250,7 +271,8 @@ int write_rows(fheram_ctx* c, const fheram_addr* addr) {
         ProfScope ps(c, "elementwise", (uint64_t)R * ws);
         hipLaunchKernelGGL((k_sub_add_norm<3>), dim3(R, ws, EW_SLICES), dim3(256), 0, c->cur, data, trhi, B, data);   // ram.rs:617,625-626
     }
-    ep_chain(c, data, data, A, prep_inv_of(c, 0), (int)c->base2d[0].size(), R, ws);                   // ram.rs:644-646
+    ep_chain(c, data, data, A, prep_inv_of(c, 0), d0, R, ws);                                         // ram.rs:644-646
+    }
     // the next read_prepare_write's side work overwrites d_prep_inv: it is ordered behind this write by an event (the gate
     // launch in front of that work is time-bounded, so it cannot be the only ordering)
     if (!capturing(c)) { hipEventRecord(c->ev_wdone, c->stream); c->wdone_pending = true; }
