@@ -78,7 +78,7 @@ def algorithmic_bytes(max_addr, ws, n_digits, atk_i64=ATK_I64):
     return read, rpw, write
 
 
-PMC_PROFILE = "profiles/r03_pmc_hbm_traffic.json"
+PMC_PROFILE = "profiles/r04_pmc_hbm_traffic.json"
 
 
 def pmc_traffic_per_launch():
@@ -574,7 +574,21 @@ def main():
 
     if not args.no_kernel_timing:
         classes = {k: ram.profile_get(k) for k in ("keyswitch", "keyswitch_fused", "keyswitch_chain_launch", "ext_product",
-                                                   "ext_product_fused", "prepare", "elementwise")}
+                                                   "ext_product_fused", "prepare", "elementwise", "read_chain_launch", "write_chain_launch")}
+        # the row chains as single launches (k_read_chain: coordinate 0's products + the alone packer levels; k_write_chain: the 12 trace
+        # steps of ct_lo X^-row + the elementwise step + write_last_step's products), against the same FP64 roof
+        d0 = len(p.base2d().v[0].d)
+        L0r = max(0, 12 - max(0, (-(-max_addr // N) - 1).bit_length()))
+        fused = {}
+        for name, n_ep, n_ks in (("read_chain_launch", d0, L0r), ("write_chain_launch", d0, 12)):
+            cl = classes[name]
+            if cl["launches"]:
+                per_ct = n_ep * FP64_PER_EP + n_ks * fp64_per_ks
+                t = cl["blocks"] * per_ct / (cl["ms"] * 1e-3) / 1e12
+                fused[name] = {"launches": cl["launches"], "ciphertexts_per_launch": cl["blocks"] / cl["launches"], "products": n_ep, "trace_steps": n_ks,
+                               "avg_launch_ms": cl["ms"] / cl["launches"], "achieved_T_fp64_instr_s": t, "frac": t / FP64_VALU_PEAK_TINSTR}
+        if fused:
+            out["fused_row_chains"] = dict(fused, note="HIP events around the launch, all-classes pass; read_chain = ram.rs:429-435 / 502-514, write_chain = ram.rs:612-646")
         kf = classes["keyswitch_fused"]
         # Dominant kernel = the fused key-switch at one workgroup per ciphertext (trace step / packer level over every
         # row of every sub-RAM).  Dependent trace steps on the same ciphertexts run as ONE launch (k_keyswitch_chain:
@@ -595,7 +609,10 @@ def main():
             avg_ms = kf_ms / kf["launches"]
             blocks = kf["blocks"] / kf["launches"]
             bytes_abi = blocks * 2 * GLWE_I64 + atk_i64              # in + out GLWE (int64 limbs) + key once
-            bytes_dev = blocks * 2 * (GLWE_I64 // 3) + atk_i64       # what the device layout must move per inner step of a chain: Y form (8 B per coefficient and column = 65 536 B per ciphertext) in and out, f64 key
+            steps_per_launch = (chain["blocks"] / chain["launches"] / blocks) if chain["launches"] else 1.0
+            # what the device layout must move per step of a chain whose steps hand over through LDS and registers: the step's key,
+            # and its share of the launch's int32 input and output (2 x 98 304 B per ciphertext per LAUNCH)
+            bytes_dev = atk_i64 + blocks * 2 * (GLWE_I64 // 2) / max(1.0, steps_per_launch)
             ach = kf["blocks"] * fp64_per_ks / (kf_ms * 1e-3) / 1e12            # T FP64 VALU instructions / s
             # PRIMARY roofline = the roof that binds this kernel: the FP64 vector ALU.  Every FP64 VALU instruction
             # (mul / add / fma / rndne: all issue at the FMA rate) is priced as one FMA slot = 2 FLOP, so that achieved

@@ -123,6 +123,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* cy = getenv("FHERAM_CHAIN_Y");
         c->chain_y = cy ? (cy[0] == '0' ? 0 : (cy[0] == '1' ? 1 : (cy[0] == '2' ? 2 : 3))) : 3;
+        const char* pz = getenv("FHERAM_PAIR_Z");
+        c->pair_z = (pz && pz[0] == '0') ? 0 : 1;
         const char* fu = getenv("FHERAM_FUSE");
         c->fuse = (fu && fu[0] == '0') ? 0 : 1;
         const char* er = getenv("FHERAM_EP_R");
@@ -156,6 +158,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product_chain<3, 4>));
     LDSATTR((&k_ext_product_chain_z<4>));
     LDSATTR((&k_ext_product_chain_r<4>));
+    LDSATTR((&k_pair_z<4>)); LDSATTR((&k_pair_z<5>));
     LDSATTR((&k_read_chain<4, 4>)); LDSATTR((&k_read_chain<5, 4>)); LDSATTR((&k_write_chain<4, 4>)); LDSATTR((&k_write_chain<5, 4>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3, 1>));

@@ -2212,6 +2212,141 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
 }
 
 // ---------------------------------------------------------------------------------------
+// k_pair_z (round 4): the packer combine (GLWEPacker, ram.rs:435,514; KS_PAIR of ks_run) split by output column, in the closed
+// form of ks_trace_z.  With A(v) = v_0 2^34 + v_1 2^17 + v_2 the integer a coefficient's limbs stand for and a' = rot(a, -t):
+//   x   = rsh1(a' - b)            its limbs are the balanced digits of  Yx = ceil((A(a') - A(b)) / 2),  top digit wrapped
+//   u   = rsh1(a' + b)            ... of Yu = ceil((A(a') + A(b)) / 2)        (rsh1 is exact on un-normalised limbs: the half a
+//                                 limb loses goes to the next one as -2^16, only the last limb rounds, up)
+//   tmp = normalize(phi_g(KS(x.mask) + (x.body, 0)))      =  window51(W),  W = e + big_2 + cmod34(big_1) 2^17 + cmod17(big_0) 2^34
+//                                                            (+- window51(Yx.body) at phi_g's source coefficient, body column)
+//   out = rot(normalize(u - tmp), +t)                     =  the digits of window51(window51(Yu) - window51(W)), moved by t with
+//                                                            the rotation's sign
+// One workgroup per (pair, output column): 3 forward transforms, 2 x 2 inverse transforms in skewed pairs, no carry chains, no
+// second normalisation walk; both inputs and the output are int32 GLWEs (the levels of the packing tree are launches).
+// ---------------------------------------------------------------------------------------
+template <int SK>
+__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_pair_z(KsArgs ka) {   // (capped as the chain kernels: the first pair level of read_prepare_write is 256 workgroups beside the gate wave)
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    static_assert((SK & 1) == 0 || SK == 5, "pairs of output limbs (+ one)");
+    constexpr int SX = 3;
+    const int tid = (int)threadIdx.x;
+    const int co = (int)blockIdx.z;
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    TwRegs twr;
+    twiddles_issue(twr, ka.tw, tid);
+    const int32_t* ap = at(ka.a);
+    const int32_t* bp = at(ka.b);
+    int32_t* op = at(ka.out);
+    double* mstage = data;                 // exchange buffer 0: Yx of the mask column, natural order
+    double* bstage = data + LDS_DATA;      // exchange buffer 1: window51(Yx) of the body column (column 0 only)
+    const int sidx0 = (tid * ka.ginv) & (2 * N - 1);
+    const int sstep = (T * ka.ginv) & (2 * N - 1);
+    // A(a') and A(b) of column `col` at the natural coefficients tid + T*k
+    auto load_ab = [&](int col, double (&aa)[E], double (&ab)[E]) {
+        RawX<KS_PAIR, SX> rw[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) load_raw<KS_PAIR, SX>(ka, ap, bp, col, tid + T * k, rw[k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const double va = __builtin_fma(__builtin_fma((double)rw[k].a[0], TWO_B, (double)rw[k].a[1]), TWO_B, (double)rw[k].a[2]);
+            aa[k] = rw[k].neg ? -va : va;
+            ab[k] = __builtin_fma(__builtin_fma((double)rw[k].b[0], TWO_B, (double)rw[k].b[1]), TWO_B, (double)rw[k].b[2]);
+        }
+    };
+    double u[E];        // window51(Yu) of this column
+    {
+        double aa[E], ab[E];
+        load_ab(1, aa, ab);
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            mstage[tid + T * k] = __builtin_floor(__builtin_fma(aa[k] - ab[k], 0.5, 0.5));
+            if (co == 1) u[k] = window51(__builtin_floor(__builtin_fma(aa[k] + ab[k], 0.5, 0.5)));
+        }
+        if (co == 0) {
+            load_ab(0, aa, ab);
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                bstage[tid + T * k] = window51(__builtin_floor(__builtin_fma(aa[k] - ab[k], 0.5, 0.5)));
+                u[k] = window51(__builtin_floor(__builtin_fma(aa[k] + ab[k], 0.5, 0.5)));
+            }
+        }
+    }
+    twiddles_commit(twr, tw, tid);      // its barrier also publishes the staged columns
+    double xh[SX][E];
+    double od[E], ec[E];
+    {
+        int sidx = sidx0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const bool ng = sidx >= N;
+            double c = mstage[sidx & (N - 1)];
+            const double d2 = take_digit(c);
+            const double d1 = take_digit(c);
+            const double d0 = cmod17(c);         // the limbs' top digit is wrapped (|Yx| reaches 2^50: the quotient can be +-2^16)
+            xh[2][k] = ng ? -d2 : d2;
+            xh[1][k] = ng ? -d1 : d1;
+            xh[0][k] = ng ? -d0 : d0;
+            double w = 0.0;
+            if (co == 0) { const double b = bstage[sidx & (N - 1)]; w = ng ? -b : b; }
+            od[k] = w;
+            ec[k] = 0.0;
+            sidx = (sidx + sstep) & (2 * N - 1);
+        }
+    }
+    OpRegs g[SX];
+#pragma unroll
+    for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + (SK - 1)) * 2 + co) * N, tid);
+    fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done
+    auto pair = [&](int j) {
+        double acc[2][E];
+#pragma unroll
+        for (int k = 0; k < E; k++) { acc[0][k] = 0.0; acc[1][k] = 0.0; }
+#pragma unroll
+        for (int r = 0; r < SX; r++) {
+            mac_regs(acc[0], xh[r], g[r]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < SX; r++) mac_regs(acc[1], xh[r], g[r]);
+        __builtin_amdgcn_sched_barrier(0);
+        ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);
+        fold_limb<SK>(od, ec, acc[0], j);
+        fold_limb<SK>(od, ec, acc[1], j - 1);
+        if (j >= 2) {
+#pragma unroll
+            for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + (j - 2)) * 2 + co) * N, tid);
+        }
+    };
+#pragma unroll 1
+    for (int j = SK - 1; j >= 1; j -= 2) pair(j);
+    if constexpr (SK & 1) {
+        double acc[1][E];
+#pragma unroll
+        for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+#pragma unroll
+        for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
+        ntt_inv<1, true, false>(acc, tw, data, tid);
+        fold_limb<SK>(od, ec, acc[0], 0);
+    }
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        double r_ = window51(u[k] - window51(od[k]));
+        const double d2 = take_digit(r_);
+        const double d1 = take_digit(r_);
+        int dst = tid + T * k + ka.t;
+        const bool ng = dst >= N;
+        if (ng) dst -= N;
+        gstore_i32(op + glwe_off(2, co), (unsigned)dst * 4u, cneg((int)d2, ng));
+        gstore_i32(op + glwe_off(1, co), (unsigned)dst * 4u, cneg((int)d1, ng));
+        gstore_i32(op + glwe_off(0, co), (unsigned)dst * 4u, cneg((int)r_, ng));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_read_chain / k_write_chain (round 4): the two dependent chains that a row goes through back to back — one workgroup per
 // ciphertext in both — as ONE launch, the ciphertext handed from the last step of one to the first step of the other in
 // registers and LDS like between the steps of either (ep_step_r, ks_trace_l).

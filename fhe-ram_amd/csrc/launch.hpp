@@ -73,6 +73,12 @@ void launch_ks(fheram_ctx* c, const KsArgs& ka, int gx, int gy) {
     // the packer combine always run split by column (their fused forms spill registers; at 2^21, where pair levels
     // have up to 1024 pairs, the split combine is 3 % faster per read than the spilling fused one was).
     constexpr bool FUSABLE = (SX == 3) && (MODE != KS_PAIR);
+    if constexpr (MODE == KS_PAIR && SX == 3 && SO == 3) {
+        if (c->pair_z) {   // the column-split combine in closed form (k_pair_z)
+            hipLaunchKernelGGL((k_pair_z<SK>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);
+            return;
+        }
+    }
     if (!FUSABLE || pick_nco(c, gx, gy) == 1) {
         hipLaunchKernelGGL((k_keyswitch<MODE, SX, SK, SO, 1>), dim3(gx, gy, 2), dim3(T), LDS_BYTES, c->cur, ka);
     } else if constexpr (FUSABLE) {

@@ -1,7 +1,7 @@
 set -x
-# Collects the round's profile set on an MI355X box (run through gpurun); summaries land in gpurun_out/r3q, from where
+# Collects the round's profile set on an MI355X box (run through gpurun); summaries land in gpurun_out/r4q, from where
 # the ones to be judged are copied into profiles/.  Counters are collected in separate passes (FETCH_SIZE, WRITE_SIZE, SQ).
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r3q; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r4q; mkdir -p $O
 for t in fetch_calib xcd_handoff xcd_barrier; do [ -x $R/tools/$t ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/$t $R/tools/$t.hip; done
 [ -x $R/tools/lds_valu_overlap ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -I$R/fhe-ram_amd/csrc -o $R/tools/lds_valu_overlap $R/tools/lds_valu_overlap.hip
 [ -x $R/tools/ntt_bench ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I$R/fhe-ram_amd/csrc -o $R/tools/ntt_bench $R/tools/ntt_bench.hip

@@ -65,26 +65,25 @@ out = {"calibration": calib,
 
 
 def dominant(kern):
-    """The dominant kernel shape = one fused trace step over 256 ciphertexts.  It runs inside k_keyswitch_chain (6 or 12 steps
-    per launch at 2^18) or as k_keyswitch<1,3,4,3,2,0>.  Limb-form chain: every step writes blocks * 98 304 B; Y-form chain
-    (round 3: intermediates as one double per coefficient and column): blocks * 65 536 B per inner step, 98 304 B for the last —
-    which gives the steps of a launch from its WRITE_SIZE."""
-    for pat in ("k_keyswitch_chain<3, 4, 3", "k_keyswitch<1, 3, 4, 3, 2, 0>"):
+    """The dominant kernel shape = one fused trace step over 256 ciphertexts.  Round 4: it runs inside k_keyswitch_chain<3,SK,3,3>
+    (the write's side-stream chain: 6 steps per launch at 2^18; PMC_CHAIN_STEPS overrides) and inside k_read_chain / k_write_chain
+    behind / in front of the products; the steps of a chain hand over through LDS and registers, so a launch reads its int32
+    input once, its keys (one per step) and writes its int32 output once: everything else stays on the CU."""
+    import os
+    steps = float(os.environ.get("PMC_CHAIN_STEPS", "6"))
+    for pat in ("k_keyswitch_chain<3, 4, 3, 3>", "k_keyswitch_chain<3, 5, 3, 3>", "k_keyswitch_chain<3, 4, 3"):
         cand = [(k, e) for k, e in kern.items() if pat in k and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e
                 and int(k.split("grid_threads=")[1]) >= 65536]
         if cand:
             k, e = max(cand, key=lambda ke: ke[1]["launches"])
             blocks = int(k.split("grid_threads=")[1]) // 512
-            yform = ("true" in k.split("grid_threads=")[0]) or ("(bool)1" in k)
-            per_ct = e["write_bytes_per_launch"] / blocks
-            steps = ((per_ct - 98304.0) / 65536.0 + 1.0) if yform else per_ct / 98304.0
-            comp = (2 * 65536 if yform else 2 * 98304)
             return {"kernel": k, "launches": e["launches"], "ciphertexts_per_step": blocks, "steps_per_launch": steps,
-                    "intermediate_form": "Y = ceil(A/2), 8 B per coefficient and column" if yform else "int32 limbs",
+                    "intermediate_form": "none in memory: the steps of a chain hand over through LDS and registers (ks_trace_l)",
                     "read_bytes_per_step": e["read_bytes_per_launch"] / steps, "write_bytes_per_step": e["write_bytes_per_launch"] / steps,
                     "hbm_bytes_per_launch": (e["read_bytes_per_launch"] + e["write_bytes_per_launch"]) / steps,
-                    "note": "hbm_bytes_per_launch is per STEP (one trace step over all ciphertexts = what bench.py's roofline calls a launch); "
-                            f"compulsory for the device layout of an inner step: {comp} B per ciphertext + the 786 432 B key"}
+                    "note": "hbm_bytes_per_launch is per STEP (one trace step over all ciphertexts = what bench.py's roofline calls a launch): "
+                            "the launch's bytes / its steps; compulsory per launch for the device layout: 2 x 98 304 B per ciphertext (int32 "
+                            "in and out) + 786 432 B of key per step"}
     return None
 
 
