@@ -9,7 +9,7 @@ from _pkg import load_package
 pkg = load_package()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 ram = pkg.Ram.new_from_ram_params(4, [3, 3, 3, 3], 1 << 12)
-for kind, name, ns in ((0, "trace chain", (2, 3, 4, 6, 8, 12)), (1, "product chain", (2, 3, 4, 6))):
+for kind, name, ns in ((0, "trace chain", (2, 3, 4, 6, 8, 12)), (1, "product chain", (2, 3, 4))):
     pts = []
     for n in ns:
         ram.bench_chain(kind, 256, n, 20)

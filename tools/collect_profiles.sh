@@ -38,3 +38,8 @@ python tools/chain_bench.py 256 600 > $O/chain_bench.txt 2>&1
 ./tools/ntt_bench > $O/ntt_bench.txt 2>&1
 ./tools/xcd_handoff > $O/xcd_handoff.txt 2>&1
 ./tools/xcd_barrier > $O/xcd_barrier.txt 2>&1
+python tools/chain_ab.py 5 100 > $O/chain_ab.txt 2>&1
+python tools/chain_n.py > $O/chain_n.txt 2>&1
+FHERAM_SAFE=1 python bench.py --no-cpu-baseline > $O/bench_safe.json 2> $O/bench_safe.err
+FHERAM_PRE_INV=2 python bench.py --no-cpu-baseline > $O/bench_event_fork.json 2> $O/bench_event_fork.err
+[ -f fhe-ram_amd/libfheram_stamp.so ] && FHERAM_LIB=$R/fhe-ram_amd/libfheram_stamp.so python tools/stamp_z.py > $O/stamps_chain_step.txt 2>&1

@@ -14,9 +14,9 @@ for rep in range(3):
     L.fheram_debug_stamps(ram._h, st, 192)
     s = np.array([int(x) for x in st], dtype=np.int64)
     t0 = s[0]
-    print(f"== rep {rep}: inner step of k_keyswitch_chain<3,4,3,2> (ks_trace_z), batch 256, wave 0 of workgroup 0; shader-clock ticks since the step began")
-    print(f"  Y of both columns loaded and staged           {s[1]-t0:8d}")
-    print(f"  barrier, gathers through phi_g, digits        {s[2]-t0:8d}")
+    print(f"== rep {rep}: inner step of k_keyswitch_chain<3,4,3,3> (ks_trace_l; FHERAM_CHAIN_Y=2: ks_trace_z), batch 256, wave 0 of workgroup 0; shader-clock ticks since the step began")
+    print(f"  own coefficients taken from LDS / registers   {s[1]-t0:8d}")
+    print(f"  gathers through phi_g, digits                 {s[2]-t0:8d}")
     print(f"  three forward transforms                      {s[3]-t0:8d}")
     prev = s[3]
     for ci in range(2):
