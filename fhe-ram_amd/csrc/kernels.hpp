@@ -1285,29 +1285,11 @@ __device__ __forceinline__ void fold_limb(double (&od)[E], double (&ec)[E], cons
         for (int k = 0; k < E; k++) od[k] = __builtin_fma(cmod17(acc[k]), TWO_2B, od[k]);
     }
 }
-#ifndef FK_Z_BI
-#define FK_Z_BI 2          // inverse transforms per batch in ks_trace_z
-#endif
-#ifndef FK_Z_PREFETCH
-#define FK_Z_PREFETCH 0    // ks_trace_z: operand polynomials (0..3) of the next limbs requested before the inverse transforms (the others behind them)
-#endif
 #ifndef FK_Z_SKEW
 #define FK_Z_SKEW 1          // ks_trace_z: the two inverse transforms of a batch half a phase apart (ntt_inv2_skew)
 #endif
-#ifndef FK_Z_EARLY
-#define FK_Z_EARLY 0    // ks_trace_z: the first operands of a column requested ahead of it (in front of the forward transforms / behind the other column's last transforms): measured neutral (37.68 against 37.64 us per step), 8 registers more: off
-#endif
 #ifndef FK_Z_SKEW_ODD
 #define FK_Z_SKEW_ODD 0
-#endif
-#ifndef FK_Z_UNROLL_PAIRS
-#define FK_Z_UNROLL_PAIRS 0
-#endif
-#ifndef FK_Z_UNROLL_COLS
-#define FK_Z_UNROLL_COLS 1
-#endif
-#ifndef FK_Z_PARK
-#define FK_Z_PARK 1        // ks_trace_z: the body column's V parked in LDS while the mask column is produced
 #endif
 template <int SK, bool IN_Y, bool OUT_Y>
 __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool load_tw, const int tid, const bool stamp_on = false) {
@@ -1377,8 +1359,6 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
         for (int r = 0; r < SX; r++)
             if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
     };
-    constexpr int PF = FK_Z_PREFETCH;   // operand polynomials of the next limb requested BEFORE the transforms (the others behind them)
-    fetch(SK - 1, 1, 0, FK_Z_EARLY ? SX : PF);   // FK_Z_EARLY: all of them (no column starts with an exposed round trip: 4-5k ticks per column in the stamps)
     YSTAMP(2);
     fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
     YSTAMP(3);
@@ -1386,35 +1366,24 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
     // buffers 0 and 1; this wave is through the forward transforms, whose wave-local exchanges are the only other accesses
     // to that region, and the cross-wave reads of their first exchange were fenced by a barrier inside it)
     double* park = data + 2 * LDS_DATA + (tid >> 6) * (64 * (E + 1)) + (tid & 63);
-    if constexpr (FK_Z_PARK) {
 #pragma unroll
-        for (int k = 0; k < E; k++) park[64 * k] = v0[k];
-    }
+    for (int k = 0; k < E; k++) park[64 * k] = v0[k];
 
-#if FK_Z_UNROLL_COLS
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
-    for (int ci = 0; ci < 2; ci++) {
+    for (int ci = 0; ci < 2; ci++) {   // (unrolled: what is live across a column differs between the two)
         const int co = 1 - ci;
         double od[E], ec[E];
-        if constexpr (FK_Z_PARK) {
-            if (co == 1) {
+        if (co == 1) {
 #pragma unroll
-                for (int k = 0; k < E; k++) od[k] = v1[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < E; k++) od[k] = park[64 * k];
-            }
+            for (int k = 0; k < E; k++) od[k] = v1[k];
         } else {
 #pragma unroll
-            for (int k = 0; k < E; k++) od[k] = (co == 1) ? v1[k] : v0[k];
+            for (int k = 0; k < E; k++) od[k] = park[64 * k];
         }
 #pragma unroll
         for (int k = 0; k < E; k++) ec[k] = 0.0;
-        if constexpr (!FK_Z_EARLY) fetch(SK - 1, co, PF, SX);   // (FK_Z_EARLY: requested in front of the forward transforms / behind column 1's last transforms)
-        if constexpr ((SK & 1) && FK_Z_BI == 2) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
+        fetch(SK - 1, co, 0, SX);
+        if constexpr (SK & 1) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
         // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
         auto batch = [&](auto nb_tag, int j) {
             constexpr int NB = decltype(nb_tag)::value;
@@ -1436,12 +1405,6 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
                 for (int r = 0; r < SX; r++) mac_regs(acc[NB - 1], xh[r], g[r]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the next limbs' first operands (or the next column's): requested HERE, their fetch runs under the transforms
-            if constexpr (PF > 0) {
-                if (j >= NB) fetch(j - NB, co, 0, PF);
-                else if (ci == 0) fetch(SK - 1, 0, 0, PF);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
             if constexpr (NB == 2) {
                 if constexpr (FK_Z_SKEW_ODD) ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);   // (5-limb keys: six spilled registers with the skewed pair, none without)
@@ -1454,31 +1417,19 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
             }
-            if constexpr (PF < SX) {   // the rest of the next limb's operands: their fetch runs under the fold and the first products
-                if (j >= NB) fetch(j - NB, co, PF, SX);
-                else if (FK_Z_EARLY && ci == 0) fetch(SK - 1, 0, PF, SX);   // column 0's first operands: under column 1's window and stores
-            }
+            if (j >= NB) fetch(j - NB, co, 0, SX);   // the next limbs' operands: their fetch runs under the first products
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         };
-        if constexpr (FK_Z_BI == 2) {
-#if FK_Z_UNROLL_PAIRS
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
-            for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
-            if constexpr (SK & 1) batch(std::integral_constant<int, 1>{}, 0);
+        for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
+        batch(std::integral_constant<int, 1>{}, 0);
         } else {
 #pragma unroll 1
-            for (int j = SK - 1; j >= 0; j--) batch(std::integral_constant<int, 1>{}, j);
-        }
-        } else {
-#pragma unroll 1
-        for (int j = SK - 1; j >= 0; j -= FK_Z_BI) {
-            const bool two = FK_Z_BI == 2 && j >= 1;
-            double acc[FK_Z_BI][E];
+        for (int j = SK - 1; j >= 0; j -= 2) {
+            const bool two = j >= 1;    // (always, for an even limb count; written as a condition: the register allocator's result depends on the shape of this loop)
+            double acc[2][E];
 #pragma unroll
-            for (int b = 0; b < FK_Z_BI; b++)
+            for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int k = 0; k < E; k++) acc[b][k] = 0.0;
             // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
@@ -1489,36 +1440,24 @@ __device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool l
                 if (two) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (FK_Z_BI == 2) {
-                if (two) {
+            if (two) {
 #pragma unroll
-                    for (int r = 0; r < SX; r++) mac_regs(acc[FK_Z_BI - 1], xh[r], g[r]);
-                }
+                for (int r = 0; r < SX; r++) mac_regs(acc[1], xh[r], g[r]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the next limbs' first operands (or the next column's): requested HERE, their fetch runs under the transforms
-            if constexpr (PF > 0) {
-                if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, 0, PF);
-                else if (ci == 0) fetch(SK - 1, 0, 0, PF);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
             if (two) {
-                if constexpr (FK_Z_SKEW && FK_Z_BI == 2) ntt_inv2_skew<true, false>(*reinterpret_cast<double(*)[2][E]>(&acc[0]), tw, data, data + LDS_DATA, tid);
-                else ntt_inv<FK_Z_BI, true, false>(acc, tw, data, tid);
+                if constexpr (FK_Z_SKEW) ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);
+                else ntt_inv<2, true, false>(acc, tw, data, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
-                fold_limb<SK>(od, ec, acc[FK_Z_BI - 1], j - 1);
+                fold_limb<SK>(od, ec, acc[1], j - 1);
             } else {
                 ntt_inv<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
             }
-            if constexpr (PF < SX) {   // the next limb's operands: their fetch runs under the first products (requested in FRONT of the fold, the compiler
-                                       // does not come back: clang 22 of ROCm 7.2 loops forever on that variant)
-                if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, PF, SX);
-                else if (FK_Z_EARLY && ci == 0) fetch(SK - 1, 0, PF, SX);   // column 0's first operands: under column 1's window and stores
-            }
+            if (j >= 2) fetch(j - 2, co, 0, SX);   // the next limbs' operands: their fetch runs under the first products
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         }
         }
@@ -1628,8 +1567,6 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         for (int r = 0; r < SX; r++)
             if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
     };
-    constexpr int PF = FK_Z_PREFETCH;   // operand polynomials of the next limb requested BEFORE the transforms (the others behind them)
-    fetch(SK - 1, 1, 0, FK_Z_EARLY ? SX : PF);   // FK_Z_EARLY: all of them (no column starts with an exposed round trip: 4-5k ticks per column in the stamps)
     YSTAMP(2);
     fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
     YSTAMP(3);
@@ -1641,12 +1578,8 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
     double y1n[E];   // column 1's output Y, on its way to buffer 2 (the next step's mask staging)
 #pragma unroll
     for (int k = 0; k < E; k++) y1n[k] = 0.0;
-#if FK_Z_UNROLL_COLS
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
-    for (int ci = 0; ci < 2; ci++) {
+    for (int ci = 0; ci < 2; ci++) {   // (unrolled: what is live across a column differs between the two)
         const int co = 1 - ci;
         double od[E], ec[E];
         if (co == 1) {
@@ -1668,8 +1601,8 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         }
 #pragma unroll
         for (int k = 0; k < E; k++) ec[k] = 0.0;
-        if constexpr (!FK_Z_EARLY) fetch(SK - 1, co, PF, SX);   // (FK_Z_EARLY: requested in front of the forward transforms / behind column 1's last transforms)
-        if constexpr ((SK & 1) && FK_Z_BI == 2) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
+        fetch(SK - 1, co, 0, SX);
+        if constexpr (SK & 1) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
         // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
         auto batch = [&](auto nb_tag, int j) {
             constexpr int NB = decltype(nb_tag)::value;
@@ -1691,12 +1624,6 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
                 for (int r = 0; r < SX; r++) mac_regs(acc[NB - 1], xh[r], g[r]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the next limbs' first operands (or the next column's): requested HERE, their fetch runs under the transforms
-            if constexpr (PF > 0) {
-                if (j >= NB) fetch(j - NB, co, 0, PF);
-                else if (ci == 0) fetch(SK - 1, 0, 0, PF);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
             if constexpr (NB == 2) {
                 if constexpr (FK_Z_SKEW_ODD) ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);   // (5-limb keys: six spilled registers with the skewed pair, none without)
@@ -1709,31 +1636,19 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
             }
-            if constexpr (PF < SX) {   // the rest of the next limb's operands: their fetch runs under the fold and the first products
-                if (j >= NB) fetch(j - NB, co, PF, SX);
-                else if (FK_Z_EARLY && ci == 0) fetch(SK - 1, 0, PF, SX);   // column 0's first operands: under column 1's window and stores
-            }
+            if (j >= NB) fetch(j - NB, co, 0, SX);   // the next limbs' operands: their fetch runs under the first products
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         };
-        if constexpr (FK_Z_BI == 2) {
-#if FK_Z_UNROLL_PAIRS
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
-            for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
-            if constexpr (SK & 1) batch(std::integral_constant<int, 1>{}, 0);
+        for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
+        batch(std::integral_constant<int, 1>{}, 0);
         } else {
 #pragma unroll 1
-            for (int j = SK - 1; j >= 0; j--) batch(std::integral_constant<int, 1>{}, j);
-        }
-        } else {
-#pragma unroll 1
-        for (int j = SK - 1; j >= 0; j -= FK_Z_BI) {
-            const bool two = FK_Z_BI == 2 && j >= 1;
-            double acc[FK_Z_BI][E];
+        for (int j = SK - 1; j >= 0; j -= 2) {
+            const bool two = j >= 1;    // (always, for an even limb count; written as a condition: the register allocator's result depends on the shape of this loop)
+            double acc[2][E];
 #pragma unroll
-            for (int b = 0; b < FK_Z_BI; b++)
+            for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int k = 0; k < E; k++) acc[b][k] = 0.0;
             // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
@@ -1744,36 +1659,25 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
                 if (two) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (FK_Z_BI == 2) {
-                if (two) {
+            if (two) {
 #pragma unroll
-                    for (int r = 0; r < SX; r++) mac_regs(acc[FK_Z_BI - 1], xh[r], g[r]);
-                }
+                for (int r = 0; r < SX; r++) mac_regs(acc[1], xh[r], g[r]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the next limbs' first operands (or the next column's): requested HERE, their fetch runs under the transforms
-            if constexpr (PF > 0) {
-                if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, 0, PF);
-                else if (ci == 0) fetch(SK - 1, 0, 0, PF);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
             if (two) {
-                if constexpr (FK_Z_SKEW && FK_Z_BI == 2) ntt_inv2_skew<true, false>(*reinterpret_cast<double(*)[2][E]>(&acc[0]), tw, data, data + LDS_DATA, tid);
-                else ntt_inv<FK_Z_BI, true, false>(acc, tw, data, tid);
+                ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
-                fold_limb<SK>(od, ec, acc[FK_Z_BI - 1], j - 1);
+                fold_limb<SK>(od, ec, acc[1], j - 1);
             } else {
                 ntt_inv<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
             }
-            if constexpr (PF < SX) {   // the next limb's operands: their fetch runs under the first products (requested in FRONT of the fold, the compiler
-                                       // does not come back: clang 22 of ROCm 7.2 loops forever on that variant)
-                if (j >= FK_Z_BI) fetch(j - FK_Z_BI, co, PF, SX);
-                else if (FK_Z_EARLY && ci == 0) fetch(SK - 1, 0, PF, SX);   // column 0's first operands: under column 1's window and stores
-            }
+            // the next limbs' operands: their fetch runs under the first products (requested in FRONT of the fold, the compiler does not
+            // come back: clang 22 of ROCm 7.2 loops forever on that variant)
+            if (j >= 2) fetch(j - 2, co, 0, SX);
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         }
         }
