@@ -7,6 +7,10 @@
 //   k_keyswitch<>  glwe_automorphism family, trace step, packer combine, GGSW inversion
 //                  (ram.rs:435,457,540,572,616,621; coordinate_prepared.rs:138)
 //   k_sub_add_norm / k_rotate   write-path elementwise steps (ram.rs:574-576,617-629)
+//   k_read_chain / k_write_chain (round 4)  a row's product chain and trace chain (ram.rs:429-435,502-514 / 612-646) as one
+//                  launch each: ep_step_r + ks_trace_l, the normalisation in closed form, steps handed over in LDS / registers
+//   k_keyswitch_chain / k_ext_product_chain(_r)  the same chains on their own; k_pair_z  the column-split packer combine
+//   k_trace_tail / k_chain_mid  dependent chains on few ciphertexts with in-kernel hand-offs between workgroups of one XCD
 //
 // Device GLWE layout: int32 [limb][col][N] (the host's int64 layout narrowed; limbs are
 // normalised to 17 bits so nothing is lost).  Prepared operands: double, transform domain,
