@@ -490,6 +490,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Weak scaling of ONE sharded RAM: the reference point is the same op on an unsharded RAM of the per-GPU size, measured HERE,
+    # on rank 0's GPU, in this run (the other ranks wait): weak_scaling_efficiency = T(1) / T(N).  `value` stays the raw ops/s
+    # of the RAM that was actually operated (whose size grows with N).
+    weak_ref = None
+    if sharded and not strong and world > 1:
+        if rank == 0:
+            r1 = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], 1 << args.log_max_addr, device=local_rank, **crypto)
+            p1 = r1.params
+            i1 = make_inputs(p1, ws, s_evk, p1.base2d().as_1d().size(), r1.local_rows(), 1234, 4321)
+            k1 = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(i1["atk"]), i1["atk_inv"], i1["tsk"])
+            a1 = pkg.Address(p1, list(i1["addr"]))
+            r1.load_encrypted(i1["rows"])
+            r1.stage_words(i1["words"])
+            ops1 = (lambda: r1.read(a1, k1, download=False), lambda: r1.read_prepare_write(a1, k1, download=False), lambda: r1.write(None, a1, k1))
+            for _ in range(max(3, args.warmup)):
+                for fn in ops1:
+                    fn()
+                    r1.sync()
+            t1 = time.perf_counter()
+            n1 = max(5, min(args.steps, 20))
+            for _ in range(n1):
+                for fn in ops1:
+                    fn()
+                    r1.sync()
+            weak_ref = (time.perf_counter() - t1) * 1e3 / n1
+            del r1
+        if dist is not None:
+            dist.barrier()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -533,6 +562,10 @@ def main():
         "ops_weighted_by_ram_size": (None if weight == 1 else
                                      {"value": raw_ops_per_s * weight,
                                       "what": f"information only: an op on the {world}*2^{args.log_max_addr}-entry RAM counted as {world} ops of the 2^{args.log_max_addr}-entry metric"}),
+        "weak_scaling_efficiency": (None if weak_ref is None else
+                                    {"value": weak_ref / ms_per_step, "t1_ms_per_step": weak_ref, "tN_ms_per_step": ms_per_step,
+                                     "what": f"T(1) / T(N): the same step on an unsharded 2^{args.log_max_addr}-entry RAM, measured in this run on rank 0's GPU, "
+                                             f"over the step on the 2^{log_entries}-entry RAM sharded over {world} GPUs"}),
         "read_ops_s": n_rams * 1e3 / read_ms, "write_ops_s": n_rams * 1e3 / (rpw_ms + write_ms),
         "read_ms": read_ms, "read_prepare_write_ms": rpw_ms, "write_ms": write_ms,
         "per_op_split": {"what": "read_ms / read_prepare_write_ms / write_ms: a pass of the same K steps with one HIP-event pair per op "
