@@ -156,7 +156,6 @@ struct fheram_ctx {
     int pair_z = 1;                // FHERAM_PAIR_Z=0: the column-split packer combine with the limb-by-limb normalisation (k_keyswitch<KS_PAIR,...,1>) instead of k_pair_z
     int fuse = 1;                  // FHERAM_FUSE=0: a row's product chain and trace chain as two launches (and the write's elementwise step as a third) instead of k_read_chain / k_write_chain
     int ep_r = 1;                  // FHERAM_EP_R=0: the products of a fused product chain hand over through global memory as int32 limbs (k_ext_product_chain, round 3) instead of in registers / LDS (k_ext_product_chain_r)
-    int ep_z = 0;                  // FHERAM_EP_Z=0: the product chains of the fused path with the limb-by-limb normalisation (k_ext_product_chain, round 3) instead of k_ext_product_chain_z
     int safe = 0;                  // FHERAM_SAFE=1: no in-kernel hand-offs between workgroups, no gate wave (fheram.hip)
     int pre_inv = 1;
     uint64_t inv_id[2] = {0, 0};

@@ -129,8 +129,6 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         c->fuse = (fu && fu[0] == '0') ? 0 : 1;
         const char* er = getenv("FHERAM_EP_R");
         c->ep_r = (er && er[0] == '0') ? 0 : 1;
-        const char* ez = getenv("FHERAM_EP_Z");
-        c->ep_z = (ez && ez[0] == '1') ? 1 : 0;   // measured slower than the round-3 product chain (61.3 against 56.4 us per product, profiles/r04_chain_ab.txt): off
         const char* gr = getenv("FHERAM_GRAPH");
         c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
         // a captured launch sequence must be a pure function of (context, address, op): under replay the write always
@@ -156,7 +154,6 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_ext_product_fine<3, 4>));
     LDSATTR((&k_ext_product_fine<4, 5>));
     LDSATTR((&k_ext_product_chain<3, 4>));
-    LDSATTR((&k_ext_product_chain_z<4>));
     LDSATTR((&k_ext_product_chain_r<4>));
     LDSATTR((&k_pair_z<4>)); LDSATTR((&k_pair_z<5>));
     LDSATTR((&k_read_chain<4, 4>)); LDSATTR((&k_read_chain<5, 4>)); LDSATTR((&k_write_chain<4, 4>)); LDSATTR((&k_write_chain<5, 4>));

@@ -1863,181 +1863,6 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// ep_run_z (round 4): the external product of a product chain with the normalisation in closed form (see ks_trace_z):
-// res = normalize_{4 -> 3 limbs}(sum_j big_j) is the balanced digit vector of
-//        V = carry(big_3) + big_2 + cmod(big_1, 2^34) * 2^17 + cmod(big_0, 2^17) * 2^34      modulo 2^51,
-// so the output limbs of a column are independent of each other: inverse transforms in skewed pairs (ntt_inv2_skew), one
-// accumulator per coefficient instead of a carry chain.  Inside a chain the intermediate ciphertexts travel as
-// A = window51(V), ONE double per coefficient and column ([col][N] in the ciphertext's slot; k_chain_mid's products do
-// the same): the consumer takes its three digits from A in FP64 (no int32 limbs, no conversions between steps).
-//   IN_A  : the input is in that form (else an int32 GLWE)       OUT_A : the output is written in that form
-// ---------------------------------------------------------------------------------------
-#ifndef FK_EPZ_G
-#define FK_EPZ_G 2
-#endif
-#ifndef FK_EPZ_PARK
-#define FK_EPZ_PARK 1
-#endif
-#ifndef FK_EPZ_SKEW
-#define FK_EPZ_SKEW 1
-#endif
-#ifndef FK_EPZ_UNROLL_COLS
-#define FK_EPZ_UNROLL_COLS 0
-#endif
-template <int SG, bool IN_A, bool OUT_A>
-__device__ __forceinline__ void ep_run_z(GlweRef a, GlweRef res, const double* __restrict__ ggsw, const double* __restrict__ tw_g,
-                                         double* lds, bool load_tw, const int tid, const bool stamp_on = false) {
-    YSTAMP(0);
-    constexpr int SA = 3;
-    double* tw = lds;
-    double* data = lds + LDS_TW;
-    TwRegs twr;
-    if (load_tw) twiddles_issue(twr, tw_g, tid);
-    const int32_t* ap = at(a);
-    int32_t* rp = at(res);
-    double x0[SA][E], x1[SA][E];   // digits of column 0 / column 1 of a
-    OpRegs g[SA];
-    auto load_digits = [&](int col, double (&x)[SA][E]) {
-        if constexpr (IN_A) {
-            const double* yp = reinterpret_cast<const double*>(ap) + (long)col * N;
-            double av[E];
-#pragma unroll
-            for (int k = 0; k < E; k++) av[k] = gload_f64(yp, (unsigned)(tid + T * k) * 8u);
-#pragma unroll
-            for (int k = 0; k < E; k++) {
-                double c = av[k];
-                x[2][k] = take_digit(c);
-                x[1][k] = take_digit(c);
-                x[0][k] = c;            // A lies in the digit window: the second quotient IS the top digit
-            }
-        } else {
-            int xi[SA][E];
-#pragma unroll
-            for (int r = 0; r < SA; r++)
-#pragma unroll
-                for (int k = 0; k < E; k++) xi[r][k] = gload_i32(ap + glwe_off(r, col), (unsigned)(tid + T * k) * 4u);
-#pragma unroll
-            for (int r = 0; r < SA; r++)
-#pragma unroll
-                for (int k = 0; k < E; k++) x[r][k] = (double)xi[r][k];
-        }
-    };
-    load_digits(0, x0);
-    if (load_tw) twiddles_commit(twr, tw, tid);
-    YSTAMP(1);
-    fwd_all<SA>(x0, tw, data, tid);
-    YSTAMP(2);
-    load_digits(1, x1);
-    fwd_all<SA>(x1, tw, data, tid);
-    YSTAMP(3);
-    // x1's last polynomial waits in the third exchange buffer (this wave's own region of it: see ks_trace_z), 16 registers
-    // fewer during the limb loops; the products read it back from there
-    double* park = data + 2 * LDS_DATA + (tid >> 6) * (64 * (E + 1)) + (tid & 63);
-    if constexpr (FK_EPZ_PARK) {
-#pragma unroll
-        for (int k = 0; k < E; k++) park[64 * k] = x1[SA - 1][k];
-    }
-    auto mac_x1 = [&](double (&acc_)[E], int r, const OpRegs& gg) {
-        if (FK_EPZ_PARK && r == SA - 1) {
-            double xp[E];
-#pragma unroll
-            for (int k = 0; k < E; k++) xp[k] = park[64 * k];
-            mac_regs(acc_, xp, gg);
-        } else mac_regs(acc_, x1[r], gg);
-    };
-
-    // operand polynomial (cin, r) of output limb j, column co
-    auto opnd = [&](int cin, int r, int j, int co) { return ggsw + (long)(((2 * r + cin) * SG + j) * 2 + co) * N; };
-    static_assert(SG == 4, "two pairs of output limbs per column");
-    // the first pair's contribution to V waits in a slot nobody else reads (the step's output slot while the output is in the
-    // A form: the thread's own final store goes to the very same address; the input slot — dead behind the forward
-    // transforms' barriers, and never the chain's source since n >= 2 — when the step writes int32 limbs): no accumulator
-    // is live across the second pair's transforms
-    double* t1p = OUT_A ? reinterpret_cast<double*>(rp) : const_cast<double*>(reinterpret_cast<const double*>(ap));
-    constexpr int NG = FK_EPZ_G;   // operand register sets in the ring (2 or 3)
-    // the 12 operand polynomials of a pair of limbs in product order; polynomial q uses set q % NG and is requested NG places ahead
-    auto opq = [&](int q, int jp, int co) { return opnd((q / SA) & 1, q % SA, jp - q / (2 * SA), co); };
-#if FK_EPZ_UNROLL_COLS
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
-    for (int co = 0; co < 2; co++) {
-#pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-            const int jp = SG - 1 - 2 * pr;      // the pair (jp, jp - 1)
-            double acc[2][E];
-#pragma unroll
-            for (int k = 0; k < E; k++) { acc[0][k] = 0.0; acc[1][k] = 0.0; }
-#pragma unroll
-            for (int q = 0; q < NG; q++) load_ops(g[q], opq(q, jp, co), tid);
-#pragma unroll
-            for (int q = 0; q < 4 * SA; q++) {
-                const int b = q / (2 * SA), cin = (q / SA) & 1, r = q % SA;
-                if (cin == 0) mac_regs(acc[b], x0[r], g[q % NG]); else mac_x1(acc[b], r, g[q % NG]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q + NG < 4 * SA) load_ops(g[q % NG], opq(q + NG, jp, co), tid);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            YSTAMP(8 + (co * SG + 2 * pr) * 4);
-            if constexpr (FK_EPZ_SKEW) ntt_inv2_skew<true, true>(acc, tw, data, data + LDS_DATA, tid);
-            else ntt_inv<2, true, true>(acc, tw, data, tid);
-            YSTAMP(9 + (co * SG + 2 * pr) * 4);
-            if (pr == 0) {      // limbs 3, 2:  e + big_2
-#pragma unroll
-                for (int k = 0; k < E; k++) gstore_f64(t1p + (long)co * N, (unsigned)(tid + T * k) * 8u, carry_of(acc[0][k]) + acc[1][k]);
-            } else {            // limbs 1, 0, the first pair's part, window, output
-                double t1[E];
-#pragma unroll
-                for (int k = 0; k < E; k++) t1[k] = gload_f64(t1p + (long)co * N, (unsigned)(tid + T * k) * 8u);
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    double v = __builtin_fma(cmod34(acc[0][k]), TWO_B, t1[k]);
-                    v = __builtin_fma(cmod17(acc[1][k]), TWO_2B, v);
-                    double a_ = window51(v);
-                    if constexpr (OUT_A) {
-                        gstore_f64(reinterpret_cast<double*>(rp) + (long)co * N, (unsigned)(tid + T * k) * 8u, a_);
-                    } else {
-                        const double d2 = take_digit(a_);
-                        const double d1 = take_digit(a_);
-                        gstore_i32(rp + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
-                        gstore_i32(rp + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
-                        gstore_i32(rp + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
-                    }
-                }
-            }
-            YSTAMP(10 + (co * SG + 2 * pr) * 4);
-        }
-    }
-    YSTAMP(5);
-}
-// the product chain in that form (n >= 2: the first step reads an int32 GLWE, the last one writes one)
-template <int SG>
-__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_ext_product_chain_z(EpChainArgs ca) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (ca.done) {
-        if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
-        if (threadIdx.x == 0) {
-            const unsigned taken = atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u) + 1u;   // ciphertexts redone (fheram_mid_stats)
-            if (ca.host_count) __hip_atomic_store(ca.host_count, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    GlweRef in = ca.src;
-#pragma unroll 1
-    for (int i = 0; i < ca.n; i++) {
-        const GlweRef out = ca.buf[i & 1];
-        int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));   // see k_ext_product_chain
-        __builtin_assume(tid >= 0 && tid < T);
-        if (i == 0) ep_run_z<SG, false, true>(in, out, ca.ggsw[i], ca.tw, lds, true, tid);
-        else if (i + 1 < ca.n) ep_run_z<SG, true, true>(in, out, ca.ggsw[i], ca.tw, lds, false, tid, YSTAMP_STEP(i + 1));
-        else ep_run_z<SG, true, false>(in, out, ca.ggsw[i], ca.tw, lds, false, tid);
-        __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over
-        in = out;
-    }
-}
-
 // GLWE::trace(start, start + n) (ram.rs:457,540,572,616,621 and the packer levels in which every
 // leaf is alone) as ONE launch: n trace steps on the same ciphertext, one workgroup per ciphertext, ping-pong
 // between the workgroup's own slots of two buffers (see k_ext_product_chain).  Only the first step may read its

@@ -220,7 +220,6 @@ void launch_ep_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const do
     ca.src = src; ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.tw = c->d_tw; ca.n = d;
     for (int i = 0; i < d; i++) ca.ggsw[i] = prep + (size_t)i * fheram_ctx::GGSW;
     if (c->ep_r && d >= 2) hipLaunchKernelGGL((k_ext_product_chain_r<4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);   // closed-form normalisation, products handed over in registers / LDS
-    else if (c->ep_z && d >= 2) hipLaunchKernelGGL((k_ext_product_chain_z<4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);   // closed-form normalisation, paired inverse transforms, A form between the products
     else hipLaunchKernelGGL((k_ext_product_chain<3, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
 }
 // CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): d external products.
