@@ -294,12 +294,16 @@ constexpr int BF = FK_BF, BI = FK_BI;
 static_assert(BF <= BMAX && BI <= BMAX, "LDS holds BMAX exchange buffers");
 
 // forward transform of S polynomials, BF at a time
-template <int S, int R = 0>
+#ifndef FK_FWD_SKEW
+#define FK_FWD_SKEW 1   // ks_trace_l: the three forward transforms half a phase apart (ntt_fwd3_skew): trace step 35.8 -> 35.6 us, step 2.198 -> 2.18 ms; the same in the products: +1 % per product, not used there
+#endif
+template <int S, int R = 0, bool SKEW = false>
 __device__ __forceinline__ void fwd_all(double (&x)[S][E], const double* tw, double* data, int tid) {
+    if constexpr (SKEW && FK_FWD_SKEW && S == 3 && R == 0 && BF == 3) { ntt_fwd3_skew(x, tw, data, tid); return; }
     if constexpr (R < S) {
         constexpr int C = (S - R < BF) ? (S - R) : BF;
         ntt_fwd<C>(*reinterpret_cast<double(*)[C][E]>(&x[R]), tw, data, tid);
-        fwd_all<S, R + C>(x, tw, data, tid);
+        fwd_all<S, R + C, false>(x, tw, data, tid);
     }
 }
 
@@ -1572,7 +1576,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
             if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
     };
     YSTAMP(2);
-    fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
+    fwd_all<SX, 0, true>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
     YSTAMP(3);
     // the body column's Y goes to buffer 2 (natural order), for the gather of column 0 (own coefficient +- phi_g's source
     // coefficient), once every wave is through the forward transforms (their wave-local exchanges use that buffer too)

@@ -443,6 +443,45 @@ __device__ __forceinline__ void ntt_inv2_skew(double (&x)[2][E], const double* t
         for (int k = 0; k < E; k++) x[b][k] = reduce(x[b][k]);
 }
 
+// ---- three forward transforms, software pipelined against each other (round 4) --------------------------------------
+// As ntt_inv2_skew for the forward direction: the cross-wave exchange 0 stays common to the three polynomials (its barriers
+// are shared), the wave-local exchanges 1 and 2 of one polynomial are in flight while the wave computes the next one's pass.
+template <int X>
+__device__ __forceinline__ void xw_fwd(const double (&x)[E], double* data, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) data[lay<X>(pat<X>(tid, k))] = x[k];
+}
+template <int X>
+__device__ __forceinline__ void xr_fwd(double (&x)[E], const double* data, int tid) {
+#pragma unroll
+    for (int k = 0; k < E; k++) x[k] = data[lay<X>(pat<X + 1>(tid, k))];
+}
+__device__ __forceinline__ void ntt_fwd3_skew(double (&x)[3][E], const double* tw, double* data, int tid) {
+    static_assert(LOGE == 3 && NPASS == 4, "written for the radix-8 transform");
+    TwPass t0, t1, t2, t3;
+    fwd_twiddles<0>(t0, tw, tid);
+#pragma unroll
+    for (int b = 0; b < 3; b++) fwd_pass<0>(x[b], t0);
+    fwd_twiddles<1>(t1, tw, tid);
+    exchange_fwd<0, 3>(x, data, tid);            // cross-wave: common barriers
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        fwd_pass<1>(x[b], t1);
+        xw_fwd<1>(x[b], data + b * LDS_DATA, tid); wave_lds_fence(); xr_fwd<1>(x[b], data + b * LDS_DATA, tid);
+        if (b == 0) fwd_twiddles<2>(t2, tw, tid);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        fwd_pass<2>(x[b], t2);
+        xw_fwd<2>(x[b], data + b * LDS_DATA, tid); wave_lds_fence(); xr_fwd<2>(x[b], data + b * LDS_DATA, tid);
+        if (b == 0) fwd_twiddles<3>(t3, tw, tid);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; b++) fwd_pass<3>(x[b], t3);
+}
+
 // copy the 4096-entry twiddle table into LDS
 __device__ __forceinline__ void load_twiddles(double* tw_lds, const double* __restrict__ tw_g, int tid) {
 #pragma unroll
