@@ -310,3 +310,113 @@ def test_rsh1_closed_form(po):
             g = rng.integers(-(1 << 16), (1 << 16) + 1, size=3 * 2 * n, dtype=np.int64)
             g[4 * n:] = rng.choice(edge, size=2 * n)
         assert np.array_equal(closed_form(g), o.glwe_rsh(1, g)), (it, mode)
+
+
+# ---- round 4: the closed-form normalisation of the HIP chain kernels (csrc/kernels.hpp: fold_limb, window51, ks_trace_z / ks_trace_l,
+# ep_step_r, k_pair_z), restated in numpy float64 — every operation of it is exact on the device, so numpy reproduces the device
+# arithmetic — against the oracle's limb-by-limb code
+_B = 2.0 ** 17
+_B2 = 2.0 ** 34
+_M = 2.0 ** 51
+_C = 2.0 ** 16 + 2.0 ** 33 + 2.0 ** 50
+
+
+def _carry(x):
+    return np.floor(x / _B + 0.5)
+
+
+def _cmod(x, m):
+    return x - m * np.floor(x / m + 0.5)
+
+
+def _window51(v):
+    return v - _M * np.floor((v + _C) / _M)
+
+
+def _digits(a):
+    """balanced base-2^17 digits (d0, d1, d2) of an integer in the window, as the kernels' take_digit chain produces them"""
+    q1 = _carry(a)
+    d2 = a - q1 * _B
+    q2 = _carry(q1)
+    d1 = q1 - q2 * _B
+    return np.stack([q2, d1, d2])
+
+
+def test_closed_form_normalisation_of_big_limbs(po):
+    """vec_znx_big_normalize of SK un-normalised limbs into 3 digits (4 -> 3 and 5 -> 3: the trace keys of both parameter blocks; the
+    external product's 4 -> 3) equals the digits of window51(e + big_2 + cmod34(big_1) 2^17 + cmod17(big_0) 2^34) with e the rounded carry
+    of the extra limbs: random limbs up to the worst-case magnitude 2^47, values on rounding ties, all-extreme limbs."""
+    o = po.Oracle(po.OParams(log_n=4, max_addr=16, decomp_n=[2, 2]))
+    n = 16
+    rng = np.random.default_rng(4)
+    for sk in (4, 5):
+        for it in range(600):
+            mode = it % 4
+            if mode == 0:
+                big = rng.integers(-(1 << 47) + 1, 1 << 47, size=(sk, n), dtype=np.int64)
+            elif mode == 1:      # rounding ties of the carries: multiples of 2^16
+                big = rng.integers(-(1 << 30), 1 << 30, size=(sk, n), dtype=np.int64) * (1 << 16)
+            elif mode == 2:
+                big = rng.choice(np.array([(1 << 47) - 1, -(1 << 47) + 1, 0, 1 << 16, -(1 << 16), (1 << 16) - 1, 1 << 33, -(1 << 33)]), size=(sk, n)).astype(np.int64)
+            else:
+                big = rng.integers(-(1 << 20), 1 << 20, size=(sk, n), dtype=np.int64)
+            want = o.big_normalize(big, 3)
+            b = big.astype(np.float64)
+            e = np.zeros(n)
+            for j in range(sk - 1, 2, -1):          # the extra limbs, least significant first
+                e = _carry(b[j] + e)
+            v = e + b[2] + _cmod(b[1], _B2) * _B + _cmod(b[0], _B) * _B2
+            assert np.all(np.abs(v) < 2.0 ** 53)
+            got = _digits(_window51(v)).astype(np.int64)
+            assert np.array_equal(got, want), (sk, it, mode)
+
+
+def test_closed_form_trace_step_post_step(po):
+    """The post-step of a trace step, a <- rsh1(a) + phi(KS(rsh1(a))) normalised (ram.rs:457,514,616): limbs of rsh1(a) added to the big
+    limbs, normalised limb by limb by the oracle, against window51(Y + e + big_2 + ...) with Y = ceil(A / 2) (ks_trace_z)."""
+    o = po.Oracle(po.OParams(log_n=4, max_addr=16, decomp_n=[2, 2]))
+    n = 16
+    rng = np.random.default_rng(5)
+    for it in range(800):
+        g = rng.integers(-(1 << 16), 1 << 16, size=(3, n), dtype=np.int64)
+        if it % 3 == 1:
+            g = rng.choice(np.array([-(1 << 16), (1 << 16) - 1, 1 << 16, 0, 1, -1]), size=(3, n)).astype(np.int64)
+        # rsh1 of one column through the oracle (a GLWE has two columns: use the same limbs in both)
+        glwe = np.stack([g, g], axis=1).reshape(-1)
+        x = o.glwe_rsh(1, glwe).reshape(3, 2, n)[:, 0, :]
+        big = rng.integers(-(1 << 47) + 1, 1 << 47, size=(4, n), dtype=np.int64)
+        summed = big.copy()
+        summed[:3] += x
+        want = o.big_normalize(summed, 3)
+        a = (g[0].astype(np.float64) * _B + g[1]) * _B + g[2]
+        y = np.floor(a * 0.5 + 0.5)
+        b = big.astype(np.float64)
+        v = y + _carry(b[3]) + b[2] + _cmod(b[1], _B2) * _B + _cmod(b[0], _B) * _B2
+        got = _digits(_window51(v)).astype(np.int64)
+        assert np.array_equal(got, want), it
+
+
+def test_closed_form_pair_combine_and_write_elementwise(po):
+    """k_pair_z: rsh1 of a limb-wise SUM / DIFFERENCE of two ciphertexts (un-normalised limbs up to +-2^17) equals the digits of
+    window51(ceil((A(a) +- A(b)) / 2)), and normalize(u - tmp) of two normalised limb vectors equals the digits of window51(U - T);
+    k_write_chain: normalize(h - t + b) equals the digits of window51(A(h) - A(t) + A(b)) (ram.rs:617,625-626)."""
+    o = po.Oracle(po.OParams(log_n=4, max_addr=16, decomp_n=[2, 2]))
+    n = 16
+    rng = np.random.default_rng(6)
+
+    def whole(l):
+        l = l.astype(np.float64)
+        return (l[0] * _B + l[1]) * _B + l[2]
+    edge = np.array([-(1 << 16), (1 << 16) - 1, 1 << 16, 0, 1, -1])
+    for it in range(800):
+        pick = (lambda: rng.integers(-(1 << 16), 1 << 16, size=(3, n), dtype=np.int64)) if it % 3 else (lambda: rng.choice(edge, size=(3, n)).astype(np.int64))
+        a, b, c = pick(), pick(), pick()
+        for sgn in (1, -1):
+            v = a + sgn * b
+            want = o.glwe_rsh(1, np.stack([v, v], axis=1).reshape(-1)).reshape(3, 2, n)[:, 0, :]
+            got = _digits(_window51(np.floor((whole(a) + sgn * whole(b)) * 0.5 + 0.5))).astype(np.int64)
+            assert np.array_equal(got, want), (it, sgn)
+        want = o.glwe_normalize(np.stack([a - b, a - b], axis=1).reshape(-1)).reshape(3, 2, n)[:, 0, :]
+        assert np.array_equal(_digits(_window51(whole(a) - whole(b))).astype(np.int64), want), it
+        want = o.glwe_normalize(np.stack([a - b + c, a - b + c], axis=1).reshape(-1)).reshape(3, 2, n)[:, 0, :]
+        assert np.array_equal(_digits(_window51(whole(a) - whole(b) + whole(c))).astype(np.int64), want), it
