@@ -10,7 +10,7 @@ from _pkg import load_package
 pkg = load_package()
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-forms = [f for f in os.environ.get("AB_FORMS", "3,2,1").split(",")]   # "2": the round-4 forms (ks_trace_z, ep_run_z); "1": round 3's
+forms = [f for f in os.environ.get("AB_FORMS", "3,2,1").split(",")]   # "3": what ships (ks_trace_l + ep_step_r); "2": the closed form handed over through global memory; "1": round 3.s
 rams = {}
 for f in forms:
     os.environ["FHERAM_CHAIN_Y"] = f
