@@ -669,7 +669,7 @@ def main():
                                "timing_source": ("HIP events around the chain launches only, on their launch stream, in a pass of the same K steps "
                                                  f"that is otherwise uninstrumented ({light['elapsed'] * 1e3 / args.steps:.3f} ms per step against "
                                                  f"{ms_per_step:.3f} in the timed region)") if lightly else "HIP events around every launch (all-classes pass)",
-                               "launch_unit": "one trace step over the batch (a chain launch runs 6 or 12 of them: HIP-event time of the launch / its steps)",
+                               "launch_unit": "one trace step over the batch: HIP-event time of a pure trace-chain launch / its steps (at 2^18 the write's side-stream chain, 6 steps per launch; the other 24 trace steps of a step run inside k_read_chain / k_write_chain behind / in front of the products: fused_row_chains)",
                                "chain_launch": ({"kernel": f"k_keyswitch_chain<3,{s_evk},3,{form}>", "launches": chain["launches"],
                                                  "avg_launch_ms": (light["chain"]["ms"] if lightly else chain["ms"]) / chain["launches"],
                                                  "avg_steps_per_launch": chain["blocks"] / chain["launches"] / blocks}
@@ -680,7 +680,8 @@ def main():
             ks = classes["keyswitch"]
             if ks["launches"]:
                 cls = ks["blocks"] * fp64_per_ks / (ks["ms"] * 1e-3) / 1e12
-                out["roofline"]["whole_class"] = {"achieved_T_fp64_instr_s": cls, "frac": cls / FP64_VALU_PEAK_TINSTR,
+                out["roofline"]["whole_class"] = {"what": "every key-switch launch OUTSIDE the fused row chains: the pure trace chain, the pair levels, the trace tail and the small batches of the dependent end of an op (latency-bound)",
+                                                  "achieved_T_fp64_instr_s": cls, "frac": cls / FP64_VALU_PEAK_TINSTR,
                                                   "avg_launch_ms": ks["ms"] / ks["launches"], "avg_blocks_per_launch": ks["blocks"] / ks["launches"]}
             # SECONDARY: the same launches against HBM.  frac is on the bytes the DEVICE layout must move (int32 limbs, f64
             # key); the int64-limb ABI layout of SURVEY.md 8(d) is reported beside it, labelled.
