@@ -134,9 +134,7 @@ _SYMBOLS = [
     ("fheram_group_result_download", C.c_int, [C.c_void_p, I64P]),
     ("fheram_group_peer_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     ("fheram_group_poisoned", C.c_int, [C.c_void_p]),
-    ("fheram_selftest_modarith", C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 6),
-    ("fheram_selftest_ntt", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    ("fheram_selftest_constants", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("fheram_selftest_convolve", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]),
 ]
 
 
@@ -860,19 +858,15 @@ class Ram:
         self._chk(library().fheram_bench_external_product(self._h, batch, iters, C.byref(ms)))
         return float(ms.value)
 
-    # -- self-tests of the FP64 modular arithmetic (tests/test_gpu_modarith.py)
-    def selftest_modarith(self, a, b, acc):
-        a, b, acc = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, b, acc))
-        outs = [np.zeros_like(a) for _ in range(3)]
-        dp = lambda v: v.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
-        self._chk(library().fheram_selftest_modarith(self._h, a.size, dp(a), dp(b), dp(acc), *[dp(o) for o in outs]))
-        return outs
-
-    def selftest_ntt(self, direction: int, polys):
-        x = np.ascontiguousarray(polys, dtype=np.float64).reshape(-1, self.params.n())
-        out = np.zeros_like(x)
-        dp = lambda v: v.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
-        self._chk(library().fheram_selftest_ntt(self._h, direction, x.shape[0], dp(x), dp(out)))
+    # -- self-test of the FP64 FFT arithmetic (tests/test_gpu_fft.py)
+    def selftest_convolve(self, a, g, singles: bool = False):
+        """raw (unrounded) sums  out[0] = sum_r a_r * g_r,  out[1] = sum_r a_r * g_{r ^ 1}  of negacyclic products of int32 polynomials"""
+        a = np.ascontiguousarray(a, dtype=np.int32).reshape(-1, self.params.n())
+        g = np.ascontiguousarray(g, dtype=np.int32).reshape(-1, self.params.n())
+        assert a.shape == g.shape
+        out = np.zeros((2, self.params.n()), dtype=np.float64)
+        ip = lambda v: v.ctypes.data_as(C.POINTER(C.c_int32))   # noqa: E731
+        self._chk(library().fheram_selftest_convolve(self._h, a.shape[0], ip(a), ip(g), out.ctypes.data_as(C.POINTER(C.c_double)), int(singles)))
         return out
 
     def bench_chain(self, kind: int, batch: int, n: int, iters: int) -> float:

@@ -17,32 +17,9 @@ using namespace fk;
 
 namespace {
 
-typedef unsigned __int128 u128;
 thread_local std::string g_create_err;
 
-uint64_t mulmod_u(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % P_U64); }
-uint64_t powmod_u(uint64_t a, uint64_t e) {
-    uint64_t r = 1;
-    while (e) { if (e & 1) r = mulmod_u(r, a); a = mulmod_u(a, a); e >>= 1; }
-    return r;
-}
-double centred(uint64_t v) { return v > P_U64 / 2 ? -(double)(P_U64 - v) : (double)v; }
-unsigned brv(unsigned x, int bits) { unsigned r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
-
-// Twiddle table in the LDS layout of ntt_dev.hpp: W[2^s + J] (W[i] = psi^bitrev12(i)) is stored
-// at 2^s + j*E^Q + hi with s = LOGE*Q + u, J = hi*2^u + j.
-std::vector<double> make_twiddles() {
-    std::vector<double> tw(N, 0.0);
-    for (int s = 0; s < LOGN; s++) {
-        const int Q = s / LOGE, u = s % LOGE, HQ = 1 << (LOGE * Q);
-        for (int J = 0; J < (1 << s); J++) {
-            const int hi = J >> u, j = J & ((1 << u) - 1);
-            const uint64_t w = powmod_u(PSI_8192, brv((unsigned)((1 << s) + J), LOGN));
-            tw[(1 << s) + j * HQ + hi] = centred(w);
-        }
-    }
-    return tw;
-}
+// Twiddle table of the transforms: fk::make_fft_twiddles() (fft_dev.hpp).
 
 struct ProfCls {
     uint64_t launches = 0, blocks = 0;

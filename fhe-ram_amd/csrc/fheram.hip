@@ -122,7 +122,7 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
         const char* ch = getenv("FHERAM_CHAIN");
         c->chain = (ch && ch[0] == '0') ? 0 : 1;
         const char* cy = getenv("FHERAM_CHAIN_Y");
-        c->chain_y = cy ? (cy[0] == '0' ? 0 : (cy[0] == '1' ? 1 : (cy[0] == '2' ? 2 : 3))) : 3;
+        c->chain_y = (cy && cy[0] == '0') ? 0 : 3;
         const char* pz = getenv("FHERAM_PAIR_Z");
         c->pair_z = (pz && pz[0] == '0') ? 0 : 1;
         const char* fu = getenv("FHERAM_FUSE");
@@ -158,12 +158,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     LDSATTR((&k_pair_z<4>)); LDSATTR((&k_pair_z<5>));
     LDSATTR((&k_read_chain<4, 4>)); LDSATTR((&k_read_chain<5, 4>)); LDSATTR((&k_write_chain<4, 4>)); LDSATTR((&k_write_chain<5, 4>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
-    LDSATTR((&k_keyswitch_chain<3, 4, 3, 1>));
-    LDSATTR((&k_keyswitch_chain<3, 4, 3, 2>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3, 3>));
     LDSATTR((&k_keyswitch_chain<3, 5, 3, 3>));
-    LDSATTR((&k_keyswitch_chain<3, 5, 3, 2>));
-    LDSATTR((&k_keyswitch_chain<3, 5, 3, 1>));
     LDSATTR((&k_trace_tail<3, 4, 3>));
     LDSATTR((&k_chain_mid<false, 4, 3, 2>)); LDSATTR((&k_chain_mid<false, 5, 3, 2>)); LDSATTR((&k_chain_mid<true, 4, 3, 2>));
     LDSATTR((&k_chain_mid<false, 4, 1, 1>)); LDSATTR((&k_chain_mid<false, 5, 1, 1>));
@@ -192,8 +188,8 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
 #undef LDSATTR_KS4
 #undef LDSATTR
 
-    std::vector<double> tw = make_twiddles();
-    c->ninv = centred(powmod_u((uint64_t)N, P_U64 - 2));
+    std::vector<double> tw = make_fft_twiddles();
+    c->ninv = 1.0 / (double)NC;   // the inverse transform's 1/n, folded into every prepared operand (a power of two: exact)
     CCHK(hipMalloc(&c->d_tw, N * sizeof(double)));
     CCHK(hipMemcpy(c->d_tw, tw.data(), N * sizeof(double), hipMemcpyHostToDevice));
     const size_t G = fheram_ctx::GLWE, nrow = (size_t)c->ws * c->rows;

@@ -17,7 +17,7 @@
 // scaled by 1/N, stored so that thread t's elements (2kk, 2kk+1) are one 16-byte word at
 // [kk*T + t] (coalesced 16 B/lane loads).
 #pragma once
-#include "ntt_dev.hpp"
+#include "fft_dev.hpp"
 #include <type_traits>
 
 namespace fk {
@@ -156,58 +156,75 @@ __device__ __forceinline__ void gstore_i32(int32_t* base, unsigned byte_off, int
 }
 
 // ---------------------------------------------------------------------------------------
-// k_prepare: forward transform of `npoly` small polynomials into prepared form.  One transform at a time: the twiddle table and
-// ONE exchange buffer of LDS (LDS_PREPARE_BYTES), so that two workgroups share a CU and the 288 polynomials of an address
-// (6 digits at 2^18) are one round of workgroups on 256 CUs instead of two.
+// k_prepare: forward transform of `npoly` small polynomials into prepared form, TWO per workgroup (the unit of the transforms
+// is a pair, fft_dev.hpp; the last workgroup of an odd count transforms one): the twiddle table and two exchange buffers of
+// LDS.  The 288 polynomials of an address (6 digits at 2^18) are 144 workgroups: one round on 256 CUs.
+// The prepared operand carries the inverse transform's 1/n (a power of two: exact).
 // ginv != 0: the polynomial is first mapped through phi_g (g = ginv^-1 mod 2N), i.e. the prepared
-// operand is NTT(phi_g(K)).  Automorphism keys are stored this way so that the key-switch can apply
+// operand is FFT(phi_g(K)).  Automorphism keys are stored this way so that the key-switch can apply
 // phi_g to its INPUT instead of to every output limb:  phi_g(sum_r x_r * K_r) = sum_r phi_g(x_r) * phi_g(K_r).
 // ---------------------------------------------------------------------------------------
-constexpr size_t LDS_PREPARE_BYTES = (size_t)(LDS_TW + LDS_DATA) * sizeof(double);
+constexpr size_t LDS_PREPARE_BYTES = (size_t)(LDS_TW + 2 * LDS_DATA) * sizeof(double);
 __global__ __launch_bounds__(T) void k_prepare(const int32_t* __restrict__ in, double* __restrict__ out,
-                                               const double* __restrict__ tw_g, double ninv, int ginv) {
+                                               const double* __restrict__ tw_g, double ninv, int ginv, int npoly) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
-    const int tid = threadIdx.x;
+    const int tid = vt((int)threadIdx.x);
     TwRegs twr;
-    twiddles_issue(twr, tw_g, tid);            // the table and the polynomial in ONE round trip (the commit's barrier comes after both)
-    const int32_t* src = in + (long)blockIdx.x * N;
-    int v[E];
-    if (ginv == 0) {
+    twiddles_issue(twr, tw_g, tid);            // the table and the polynomials in ONE round trip (the commit's barrier comes after both)
+    const int p0 = 2 * (int)blockIdx.x;
+    const bool two = p0 + 1 < npoly;           // (workgroup uniform)
+    int v[2][E];
 #pragma unroll
-        for (int k = 0; k < E; k++) v[k] = src[tid + T * k];
-    } else {   // destination i' takes +-source i, i = i' * ginv mod 2N (one-off gather at key load)
+    for (int b = 0; b < 2; b++) {
+        const int32_t* src = in + (long)(p0 + ((b == 1 && two) ? 1 : 0)) * N;
+        if (ginv == 0) {
 #pragma unroll
-        for (int k = 0; k < E; k++) {
-            const int s = ((tid + T * k) * ginv) & (2 * N - 1);
-            const int w = src[s & (N - 1)];
-            v[k] = s >= N ? -w : w;
+            for (int k = 0; k < E; k++) v[b][k] = src[tid + T * k];
+        } else {   // destination i' takes +-source i, i = i' * ginv mod 2N (one-off gather at key load)
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const int s = ((tid + T * k) * ginv) & (2 * N - 1);
+                const int w = src[s & (N - 1)];
+                v[b][k] = s >= N ? -w : w;
+            }
         }
     }
     twiddles_commit(twr, tw, tid);
-    double x[1][E];
+    double x[2][E];
 #pragma unroll
-    for (int k = 0; k < E; k++) x[0][k] = (double)v[k];
-    ntt_fwd<1>(x, tw, data, tid);
-    double2* o = reinterpret_cast<double2*>(out + (long)blockIdx.x * N);
+    for (int b = 0; b < 2; b++)
 #pragma unroll
-    for (int kk = 0; kk < E / 2; kk++) {
-        double2 v;
-        v.x = reduce(mulmod(reduce(x[0][2 * kk]), ninv));
-        v.y = reduce(mulmod(reduce(x[0][2 * kk + 1]), ninv));
-        o[kk * T + tid] = v;
+        for (int k = 0; k < E; k++) x[b][k] = (double)v[b][k];
+    ntt_fwd<2>(x, tw, data, tid);
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        if (b == 1 && !two) break;
+        double2* o = reinterpret_cast<double2*>(out + (long)(p0 + b) * N);
+#pragma unroll
+        for (int kk = 0; kk < E / 2; kk++) {
+            double2 w;
+            w.x = x[b][2 * kk] * ninv;
+            w.y = x[b][2 * kk + 1] * ninv;
+            o[kk * T + tid] = w;
+        }
     }
 }
 
-// acc[k] += x[k] (.) g[k]   for one prepared polynomial
+// acc += x (.) g for one prepared polynomial: 4 complex points per thread, (re, im) = elements (2kk, 2kk+1); 4 FMAs per point
+__device__ __forceinline__ void cmac(double& ar, double& ai, double xr, double xi, double gr, double gi) {
+    ar = __builtin_fma(xr, gr, ar);
+    ar = __builtin_fma(-xi, gi, ar);
+    ai = __builtin_fma(xr, gi, ai);
+    ai = __builtin_fma(xi, gr, ai);
+}
 __device__ __forceinline__ void mac_poly(double (&acc)[E], const double (&x)[E], const double* __restrict__ g, int tid) {
     const double2* gp = reinterpret_cast<const double2*>(g);
 #pragma unroll
     for (int kk = 0; kk < E / 2; kk++) {
         const double2 v = gp[kk * T + tid];
-        acc[2 * kk] = macmod(acc[2 * kk], x[2 * kk], v.x);
-        acc[2 * kk + 1] = macmod(acc[2 * kk + 1], x[2 * kk + 1], v.y);
+        cmac(acc[2 * kk], acc[2 * kk + 1], x[2 * kk], x[2 * kk + 1], v.x, v.y);
     }
 }
 
@@ -241,10 +258,7 @@ __device__ __forceinline__ void load_ops(OpRegs& o, const double* __restrict__ g
 }
 __device__ __forceinline__ void mac_regs(double (&acc)[E], const double (&x)[E], const OpRegs& o) {
 #pragma unroll
-    for (int kk = 0; kk < E / 2; kk++) {
-        acc[2 * kk] = macmod(acc[2 * kk], x[2 * kk], o.v[kk].x);
-        acc[2 * kk + 1] = macmod(acc[2 * kk + 1], x[2 * kk + 1], o.v[kk].y);
-    }
+    for (int kk = 0; kk < E / 2; kk++) cmac(acc[2 * kk], acc[2 * kk + 1], x[2 * kk], x[2 * kk + 1], o.v[kk].x, o.v[kk].y);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -525,7 +539,7 @@ template <int SA, int SG, int NCO, int STAGE = 0>
 __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
                                                             const double* __restrict__ tw_g, double* __restrict__ big) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    ep_run<SA, SG, NCO, STAGE>(a, res, ggsw, tw_g, big, lds, true, (int)threadIdx.x);
+    ep_run<SA, SG, NCO, STAGE>(a, res, ggsw, tw_g, big, lds, true, vt((int)threadIdx.x));
 }
 // CoordinatePrepared::product(_inplace) (coordinate_prepared.rs:147-177) as ONE launch: the n external products
 // of a coordinate's digits on the same ciphertext, one workgroup per ciphertext.  Step i reads what step
@@ -557,7 +571,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
 #pragma unroll 1
     for (int i = 0; i < ca.n; i++) {
         const GlweRef out = ca.buf[i & 1];
-        int tid = (int)threadIdx.x;
+        int tid = vt((int)threadIdx.x);
         asm volatile("" : "+v"(tid));   // per-step copy the optimiser cannot see through: keeps it from hoisting every
                                         // thread-index-derived address out of the step loop (56 spilled registers)
         __builtin_assume(tid >= 0 && tid < T);   // ... but it may still use the range (index patterns fold to immediates)
@@ -1025,7 +1039,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
 template <int MODE, int SX, int SK, int SO, int NCO, int STAGE = 0>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    ks_run<MODE, SX, SK, SO, NCO, STAGE>(ka, lds, true, (int)threadIdx.x);
+    ks_run<MODE, SX, SK, SO, NCO, STAGE>(ka, lds, true, vt((int)threadIdx.x));
 }
 // ---------------------------------------------------------------------------------------
 // One fused trace step (a <- rsh1(a); a <- a + phi_g(KS(a)): GLWE::trace, ram.rs:457,540,572,616,621, and the packer
@@ -1053,184 +1067,6 @@ __device__ __forceinline__ double take_digit(double& c) {
     const double d = digit_of(c, q);
     c = q;
     return d;
-}
-template <int SK, bool IN_Y, bool OUT_Y>
-__device__ __forceinline__ void ks_trace_y(const KsArgs& ka, double* lds, bool load_tw, const int tid, const bool stamp_on = false) {
-    YSTAMP(0);
-    constexpr int SX = 3, SO = 3;
-    double* tw = lds;
-    double* data = lds + LDS_TW;
-    TwRegs twr;
-    if (load_tw) twiddles_issue(twr, ka.tw, tid);
-    const int32_t* ap = at(ka.a);
-    int32_t* op = at(ka.out);
-    double* ystage = data;                    // exchange buffer 0, before any transform: Y of the mask column, natural order
-    double* bstage = data + 2 * LDS_DATA;     // third exchange buffer: the double-buffered inverse transforms leave it alone
-    static_assert((size_t)N * sizeof(double) <= (size_t)LDS_DATA * sizeof(double), "a staged column fits one exchange buffer");
-    const int sidx0 = (tid * ka.ginv) & (2 * N - 1);      // phi_g: destination i' = tid + T*k takes +-source i = i' * ginv mod 2N
-    const int sstep = (T * ka.ginv) & (2 * N - 1);
-
-    // Y of the input at the natural coefficients tid + T*k.  Only the mask column (1) is needed in front of the forward
-    // transforms; the body column (0) is fetched and parked in LDS at the top of ITS limb loop (FK_LATE_BODY): eight loads,
-    // sixteen registers and a workgroup barrier fewer in the step's prologue
-    auto y_of = [](const RawX<KS_TRACE, SX>& r) {
-        double a_ = __builtin_fma(__builtin_fma((double)r.a[0], TWO_B, (double)r.a[1]), TWO_B, (double)r.a[2]);
-        a_ = r.neg ? -a_ : a_;                                       // the rotation's sign comes before the shift
-        return __builtin_floor(__builtin_fma(a_, 0.5, 0.5));        // ceil(A / 2)
-    };
-    auto load_column = [&](int col, double (&y)[E]) {
-        if constexpr (IN_Y) {
-            const double* yp = reinterpret_cast<const double*>(ap);
-#pragma unroll
-            for (int k = 0; k < E; k++) y[k] = gload_f64(yp + (long)col * N, (unsigned)(tid + T * k) * 8u);
-        } else {
-            RawX<KS_TRACE, SX> rw[E];
-#pragma unroll
-            for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, col, tid + T * k, rw[k]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < E; k++) y[k] = y_of(rw[k]);
-        }
-    };
-    double y1[E];
-    load_column(1, y1);
-    [[maybe_unused]] double y0[E];
-    if constexpr (!FK_LATE_BODY) load_column(0, y0);
-#pragma unroll
-    for (int k = 0; k < E; k++) ystage[tid + T * k] = y1[k];
-    YSTAMP(1);
-    if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();   // its barrier also publishes the staged column
-
-    // Phase 1: the digits of the mask column seen through phi_g, transformed
-    double xh[SX][E];
-    {
-        int sidx = sidx0;
-#pragma unroll
-        for (int k = 0; k < E; k++) {
-            const bool ng = sidx >= N;
-            double c = ystage[sidx & (N - 1)];
-            const double d2 = take_digit(c);
-            const double d1 = take_digit(c);
-            // |Y| < 2^49 + 2^33: the second quotient is below 2^16 in magnitude and IS the top digit (no wrap to take care of)
-            xh[2][k] = ng ? -d2 : d2;
-            xh[1][k] = ng ? -d1 : d1;
-            xh[0][k] = ng ? -c : c;
-            sidx = (sidx + sstep) & (2 * N - 1);
-        }
-    }
-    // the operands of column 1's first output limb: requested in front of the forward transforms (FK_EARLY_FIRST; the body
-    // column's registers are free there since FK_LATE_BODY), so that the column does not start with an exposed round trip
-    OpRegs g[SX];
-    if constexpr (FK_EARLY_FIRST) {
-#pragma unroll
-        for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + (SK - 1)) * 2 + 1) * N, tid);
-    }
-    YSTAMP(2);
-    fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before buffer 0 is overwritten
-
-    // the body column, staged for the gathers of add_body — and parked there: its owner takes it back when its turn comes,
-    // so that only ONE column's Y is held in registers during the limb loops (the mask column goes first, from the registers
-    // it already is in)
-    YSTAMP(3);
-    if constexpr (!FK_LATE_BODY) {
-        lds_barrier();                 // slower waves may still be inside the wave-local exchanges of the forward transforms
-#pragma unroll
-        for (int k = 0; k < E; k++) bstage[tid + T * k] = y0[k];
-        // published by the barriers of the first inverse transform, which precede every gather
-    }
-
-    YSTAMP(4);
-    int it = 0;
-#pragma unroll 1
-    for (int ci = 0; ci < 2; ci++) {
-        const int co = 1 - ci;
-        auto fetch = [&](int j) {
-#pragma unroll
-            for (int r = 0; r < SX; r++) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
-        };
-        if (!FK_EARLY_FIRST || co == 0) fetch(SK - 1);   // (requested earlier the operand registers spill — in front of the forward transforms, or column 0's during
-                         // column 1's last post-step: 45 us per step — or change nothing: behind the forward transforms)
-        double cq[E];                  // running quotient of this column's Y: the post-step takes its digits from the least significant one upwards, as the limbs are produced
-        if (co == 1) {
-#pragma unroll
-            for (int k = 0; k < E; k++) cq[k] = y1[k];
-        } else if constexpr (FK_LATE_BODY) {
-            // the body column of the input, fetched HERE (its round trip runs beside the operands' above) and parked in the third
-            // exchange buffer for the gathers of the body add: no transform of the limb loops touches that buffer, every wave
-            // is past the forward transforms (it has been through inverse transforms' barriers since), and the barriers of
-            // this column's first inverse transforms publish it before the first gather (limb 2)
-            load_column(0, cq);
-#pragma unroll
-            for (int k = 0; k < E; k++) bstage[tid + T * k] = cq[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < E; k++) cq[k] = bstage[tid + T * k];   // this thread's own slots
-        }
-        double carry[E], od[E];
-#pragma unroll
-        for (int k = 0; k < E; k++) { carry[k] = 0.0; od[k] = 0.0; }
-#pragma unroll 1
-        for (int j = SK - 1; j >= 0; j--) {
-            double acc[1][E];
-#pragma unroll
-            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
-#pragma unroll
-            for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
-            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
-            __builtin_amdgcn_sched_barrier(0);
-            ntt_inv<1, false, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);
-            YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);   // 3 MAC terms: no initial reduction; double-buffered exchanges
-            // next limb's operands: their latency overlaps the post-step.  One operand polynomial at a time, between the parts
-            // of the post-step (FK_SPREAD_FETCH): 12 loads per thread from all eight waves at once wait for the address unit
-            // to take them (16 cycles per wave and load), and a wave that waits there computes nothing
-            auto fetch_next = [&](int r) {
-                if (j >= 1) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
-            };
-            if constexpr (FK_SPREAD_FETCH) fetch_next(0); else { if (j >= 1) fetch(j - 1); }
-            __builtin_amdgcn_sched_barrier(0);
-            if (co == 0 && j < SX) {   // vec_znx_big_add_small_inplace of body limb j, seen through phi_g
-                int sidx = sidx0;
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    double c = bstage[sidx & (N - 1)];
-                    double d = take_digit(c);
-                    if (j <= 1) d = take_digit(c);
-                    if (j == 0) d = c;
-                    acc[0][k] += (sidx >= N) ? -d : d;
-                    sidx = (sidx + sstep) & (2 * N - 1);
-                }
-            }
-            YSTAMP(10 + (ci * SK + (SK - 1 - j)) * 4);
-            const double scale = (j == 2) ? 1.0 : ((j == 1) ? TWO_B : TWO_2B);
-#pragma unroll
-            for (int k = 0; k < E; k++) {
-                if constexpr (FK_SPREAD_FETCH) {
-                    if (k == E / 4) { __builtin_amdgcn_sched_barrier(0); fetch_next(1); __builtin_amdgcn_sched_barrier(0); }
-                    if (k == (3 * E) / 4) { __builtin_amdgcn_sched_barrier(0); fetch_next(2); __builtin_amdgcn_sched_barrier(0); }
-                }
-                double v = acc[0][k];
-                if (j < SX) {          // a + phi(KS(a)): limb j of rsh1(a) = digit j of Y
-                    const double xl = (j > 0) ? take_digit(cq[k]) : cq[k];
-                    v += xl;
-                }
-                v += carry[k];
-                const double cy = carry_of(v);
-                carry[k] = cy;
-                if (j < SO) {
-                    const double d = digit_of(v, cy);
-                    if constexpr (OUT_Y) od[k] = __builtin_fma(d, scale, od[k]);
-                    else gstore_i32(op + glwe_off(j, co), (unsigned)(tid + T * k) * 4u, (int)d);
-                }
-            }
-            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
-        }
-        if constexpr (OUT_Y) {
-            double* yo = reinterpret_cast<double*>(op) + (long)co * N;
-#pragma unroll
-            for (int k = 0; k < E; k++) gstore_f64(yo, (unsigned)(tid + T * k) * 8u, __builtin_floor(__builtin_fma(od[k], 0.5, 0.5)));
-        }
-    }
-    YSTAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1293,199 +1129,9 @@ __device__ __forceinline__ void fold_limb(double (&od)[E], double (&ec)[E], cons
         for (int k = 0; k < E; k++) od[k] = __builtin_fma(cmod17(acc[k]), TWO_2B, od[k]);
     }
 }
-#ifndef FK_Z_SKEW
-#define FK_Z_SKEW 1          // ks_trace_z: the two inverse transforms of a batch half a phase apart (ntt_inv2_skew)
-#endif
 #ifndef FK_Z_SKEW_ODD
-#define FK_Z_SKEW_ODD 0
+#define FK_Z_SKEW_ODD 0   // ks_trace_l, 5-limb keys: the skewed pair of inverse transforms (six spilled registers with it, none without)
 #endif
-template <int SK, bool IN_Y, bool OUT_Y>
-__device__ __forceinline__ void ks_trace_z(const KsArgs& ka, double* lds, bool load_tw, const int tid, const bool stamp_on = false) {
-    YSTAMP(0);
-    constexpr int SX = 3;
-    double* tw = lds;
-    double* data = lds + LDS_TW;
-    TwRegs twr;
-    if (load_tw) twiddles_issue(twr, ka.tw, tid);
-    const int32_t* ap = at(ka.a);
-    int32_t* op = at(ka.out);
-    double* ystage = data;                 // exchange buffer 0: Y of the mask column, natural order
-    double* bstage = data + LDS_DATA;      // exchange buffer 1: Y of the body column (both are free until the forward transforms)
-    const int sidx0 = (tid * ka.ginv) & (2 * N - 1);      // phi_g: destination i' = tid + T*k takes +-source i = i' * ginv mod 2N
-    const int sstep = (T * ka.ginv) & (2 * N - 1);
-
-    auto y_of = [](const RawX<KS_TRACE, SX>& r) {
-        double a_ = __builtin_fma(__builtin_fma((double)r.a[0], TWO_B, (double)r.a[1]), TWO_B, (double)r.a[2]);
-        a_ = r.neg ? -a_ : a_;                                       // the rotation's sign comes before the shift
-        return __builtin_floor(__builtin_fma(a_, 0.5, 0.5));        // ceil(A / 2)
-    };
-    auto load_column = [&](int col, double (&y)[E]) {
-        if constexpr (IN_Y) {
-            const double* yp = reinterpret_cast<const double*>(ap);
-#pragma unroll
-            for (int k = 0; k < E; k++) y[k] = gload_f64(yp + (long)col * N, (unsigned)(tid + T * k) * 8u);
-        } else {
-            RawX<KS_TRACE, SX> rw[E];
-#pragma unroll
-            for (int k = 0; k < E; k++) load_raw<KS_TRACE, SX>(ka, ap, nullptr, col, tid + T * k, rw[k]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < E; k++) y[k] = y_of(rw[k]);
-        }
-    };
-    // V of both columns starts as the column's own Y (natural order); both are staged for the gathers through phi_g
-    double v1[E], v0[E];
-    load_column(1, v1);
-    load_column(0, v0);
-#pragma unroll
-    for (int k = 0; k < E; k++) { ystage[tid + T * k] = v1[k]; bstage[tid + T * k] = v0[k]; }
-    YSTAMP(1);
-    if (load_tw) twiddles_commit(twr, tw, tid); else __syncthreads();   // its barrier also publishes the staged columns
-
-    // the digits of the mask column seen through phi_g (to be transformed), and phi_g(body) added to the body column's V
-    double xh[SX][E];
-    {
-        int sidx = sidx0;
-#pragma unroll
-        for (int k = 0; k < E; k++) {
-            const bool ng = sidx >= N;
-            double c = ystage[sidx & (N - 1)];
-            const double b = bstage[sidx & (N - 1)];
-            const double d2 = take_digit(c);
-            const double d1 = take_digit(c);
-            xh[2][k] = ng ? -d2 : d2;
-            xh[1][k] = ng ? -d1 : d1;
-            xh[0][k] = ng ? -c : c;
-            v0[k] += ng ? -b : b;
-            sidx = (sidx + sstep) & (2 * N - 1);
-        }
-    }
-    // operands of the first output limb of column 1: in flight during the forward transforms
-    OpRegs g[SX];
-    auto fetch = [&](int j, int co, int r0, int r1) {
-#pragma unroll
-        for (int r = 0; r < SX; r++)
-            if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
-    };
-    YSTAMP(2);
-    fwd_all<SX>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
-    YSTAMP(3);
-    // the body column's V waits in the third exchange buffer, in this WAVE's own region of it (the inverse transforms use
-    // buffers 0 and 1; this wave is through the forward transforms, whose wave-local exchanges are the only other accesses
-    // to that region, and the cross-wave reads of their first exchange were fenced by a barrier inside it)
-    double* park = data + 2 * LDS_DATA + (tid >> 6) * (64 * (E + 1)) + (tid & 63);
-#pragma unroll
-    for (int k = 0; k < E; k++) park[64 * k] = v0[k];
-
-#pragma unroll
-    for (int ci = 0; ci < 2; ci++) {   // (unrolled: what is live across a column differs between the two)
-        const int co = 1 - ci;
-        double od[E], ec[E];
-        if (co == 1) {
-#pragma unroll
-            for (int k = 0; k < E; k++) od[k] = v1[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < E; k++) od[k] = park[64 * k];
-        }
-#pragma unroll
-        for (int k = 0; k < E; k++) ec[k] = 0.0;
-        fetch(SK - 1, co, 0, SX);
-        if constexpr (SK & 1) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
-        // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
-        auto batch = [&](auto nb_tag, int j) {
-            constexpr int NB = decltype(nb_tag)::value;
-            double acc[NB][E];
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
-            // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
-#pragma unroll
-            for (int r = 0; r < SX; r++) {
-                mac_regs(acc[0], xh[r], g[r]);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (NB == 2) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (NB == 2) {
-#pragma unroll
-                for (int r = 0; r < SX; r++) mac_regs(acc[NB - 1], xh[r], g[r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
-            if constexpr (NB == 2) {
-                if constexpr (FK_Z_SKEW_ODD) ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);   // (5-limb keys: six spilled registers with the skewed pair, none without)
-                else ntt_inv<2, true, false>(acc, tw, data, tid);
-                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                fold_limb<SK>(od, ec, acc[0], j);
-                fold_limb<SK>(od, ec, acc[NB - 1], j - 1);
-            } else {
-                ntt_inv<1, true, false>(acc, tw, data, tid);
-                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                fold_limb<SK>(od, ec, acc[0], j);
-            }
-            if (j >= NB) fetch(j - NB, co, 0, SX);   // the next limbs' operands: their fetch runs under the first products
-            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
-        };
-#pragma unroll 1
-        for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
-        batch(std::integral_constant<int, 1>{}, 0);
-        } else {
-#pragma unroll 1
-        for (int j = SK - 1; j >= 0; j -= 2) {
-            const bool two = j >= 1;    // (always, for an even limb count; written as a condition: the register allocator's result depends on the shape of this loop)
-            double acc[2][E];
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
-            // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
-#pragma unroll
-            for (int r = 0; r < SX; r++) {
-                mac_regs(acc[0], xh[r], g[r]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (two) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (two) {
-#pragma unroll
-                for (int r = 0; r < SX; r++) mac_regs(acc[1], xh[r], g[r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
-            if (two) {
-                if constexpr (FK_Z_SKEW) ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);
-                else ntt_inv<2, true, false>(acc, tw, data, tid);
-                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                fold_limb<SK>(od, ec, acc[0], j);
-                fold_limb<SK>(od, ec, acc[1], j - 1);
-            } else {
-                ntt_inv<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
-                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                fold_limb<SK>(od, ec, acc[0], j);
-            }
-            if (j >= 2) fetch(j - 2, co, 0, SX);   // the next limbs' operands: their fetch runs under the first products
-            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
-        }
-        }
-#pragma unroll
-        for (int k = 0; k < E; k++) {
-            double a_ = window51(od[k]);
-            if constexpr (OUT_Y) {
-                double* yo = reinterpret_cast<double*>(op) + (long)co * N;
-                gstore_f64(yo, (unsigned)(tid + T * k) * 8u, __builtin_floor(__builtin_fma(a_, 0.5, 0.5)));
-            } else {
-                const double d2 = take_digit(a_);
-                const double d1 = take_digit(a_);
-                gstore_i32(op + glwe_off(2, co), (unsigned)(tid + T * k) * 4u, (int)d2);
-                gstore_i32(op + glwe_off(1, co), (unsigned)(tid + T * k) * 4u, (int)d1);
-                gstore_i32(op + glwe_off(0, co), (unsigned)(tid + T * k) * 4u, (int)a_);
-            }
-        }
-    }
-    YSTAMP(5);
-}
 
 // ---------------------------------------------------------------------------------------
 // ks_trace_l (round 4): ks_trace_z with the hand-over between the steps of a chain through LDS and registers.  Producer and
@@ -1857,7 +1503,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
 #pragma unroll 1
     for (int i = 0; i < ca.n; i++) {
         const GlweRef out = ca.buf[i & 1];
-        int tid = (int)threadIdx.x;
+        int tid = vt((int)threadIdx.x);
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
         __builtin_assume(tid >= 0 && tid < T);
         if (i == 0) ep_step_r<SG, 0, 1>(in, out, ca.ggsw[i], ca.tw, lds, true, tid, ac);
@@ -1893,7 +1539,7 @@ struct KsChainArgs {
 // file, and ANY other wave resident on the CU — the one-wave gate launch that read_prepare_write parks on the side stream is
 // enough — keeps the workgroup off that CU: a 256-workgroup launch on 256 CUs then runs in two rounds (+0.24 ms per
 // read_prepare_write, measured when the Y-form kernel first compiled to 250).  Capped so that a small wave still fits.
-template <int SX, int SK, int SO, int YF = 0>   // YF: 0 limbs, 1 Y form (ks_trace_y), 2 Y form with the closed-form normalisation (ks_trace_z), 3 the same handed over through LDS and registers (ks_trace_l)
+template <int SX, int SK, int SO, int YF = 0>   // YF: 0 int32 limbs between the steps (ks_run); 3 the intermediates as Y = ceil(A/2) with the closed-form normalisation, handed over through LDS and registers (ks_trace_l)
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (ca.pred) {
@@ -1920,7 +1566,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         ka.b = ka.a;
         ka.key = ca.key[i];
         ka.ginv = ca.ginv[i];
-        int tid = (int)threadIdx.x;
+        int tid = vt((int)threadIdx.x);
         asm volatile("" : "+v"(tid));   // see k_ext_product_chain
         __builtin_assume(tid >= 0 && tid < T);
         if constexpr (YF == 3) {
@@ -1928,16 +1574,6 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
             if (i == 0) ks_trace_l<SK, false, 1>(ka, lds, true, tid, vcarry);
             else if (i + 1 < ca.n) ks_trace_l<SK, true, 1>(ka, lds, false, tid, vcarry, YSTAMP_STEP(i));
             else ks_trace_l<SK, true, 0>(ka, lds, false, tid, vcarry);
-        } else if constexpr (YF == 2) {
-            static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
-            if (i == 0) ks_trace_z<SK, false, true>(ka, lds, true, tid);
-            else if (i + 1 < ca.n) ks_trace_z<SK, true, true>(ka, lds, false, tid, YSTAMP_STEP(i));
-            else ks_trace_z<SK, true, false>(ka, lds, false, tid);
-        } else if constexpr (YF == 1) {   // intermediates of the chain as Y = ceil(A/2), one double per coefficient (ks_trace_y); n >= 2
-            static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
-            if (i == 0) ks_trace_y<SK, false, true>(ka, lds, true, tid);
-            else if (i + 1 < ca.n) ks_trace_y<SK, true, true>(ka, lds, false, tid, YSTAMP_STEP(i));
-            else ks_trace_y<SK, true, false>(ka, lds, false, tid);
         } else {
             ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
         }
@@ -1966,7 +1602,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert((SK & 1) == 0 || SK == 5, "pairs of output limbs (+ one)");
     constexpr int SX = 3;
-    const int tid = (int)threadIdx.x;
+    const int tid = vt((int)threadIdx.x);
     const int co = (int)blockIdx.z;
     double* tw = lds;
     double* data = lds + LDS_TW;
@@ -2112,7 +1748,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
 #pragma unroll 1
         for (int i = 0; i < ra.ep.n; i++) {      // n >= 2
             const GlweRef out = ra.ep.buf[i & 1];
-            int tid = (int)threadIdx.x;
+            int tid = vt((int)threadIdx.x);
             asm volatile("" : "+v"(tid));   // see k_ext_product_chain
             __builtin_assume(tid >= 0 && tid < T);
             if (i == 0) ep_step_r<SG, 0, 1>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, true, tid, vc);
@@ -2127,7 +1763,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         ka.out = ra.ks.buf[i & 1];
         ka.key = ra.ks.key[i];
         ka.ginv = ra.ks.ginv[i];
-        int tid = (int)threadIdx.x;
+        int tid = vt((int)threadIdx.x);
         asm volatile("" : "+v"(tid));
         __builtin_assume(tid >= 0 && tid < T);
         if (i + 1 < ra.ks.n) ks_trace_l<SK, true, 1>(ka, lds, false, tid, vc);
@@ -2144,7 +1780,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         ka.out = ra.ks.buf[i & 1];
         ka.key = ra.ks.key[i];
         ka.ginv = ra.ks.ginv[i];
-        int tid = (int)threadIdx.x;
+        int tid = vt((int)threadIdx.x);
         asm volatile("" : "+v"(tid));
         __builtin_assume(tid >= 0 && tid < T);
         if (i == 0) ks_trace_l<SK, false, 1>(ka, lds, true, tid, vc);
@@ -2157,7 +1793,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
 #pragma unroll 1
     for (int i = 0; i < ra.ep.n; i++) {          // n >= 2
         const GlweRef out = ra.ep.buf[i & 1];
-        int tid = (int)threadIdx.x;
+        int tid = vt((int)threadIdx.x);
         asm volatile("" : "+v"(tid));
         __builtin_assume(tid >= 0 && tid < T);
         if (i == 0) ep_step_r<SG, 2, 1>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, false, tid, vc);
@@ -2272,7 +1908,7 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)   // the last block: every block of the launch has been placed (k_tail_gate)
         __hip_atomic_store(ta.sync + TAIL_GROUPS * 32 + 2, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (g >= ta.n_ct) return;
-    const int tid = threadIdx.x;
+    const int tid = vt((int)threadIdx.x);
     double* tw = lds;
     double* data = lds + LDS_TW;
     int* mstage = reinterpret_cast<int*>(data);
@@ -2446,61 +2082,28 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
 }
 
 #ifdef FK_STAMP
-// Diagnostic: one inverse + one forward transform with stamps between passes and exchanges.
+// Diagnostic: one inverse + one forward pair transform with stamps around them.
 __global__ __launch_bounds__(T, T / 256) void k_ntt_probe(const double* __restrict__ tw_g, double* sink) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
-    const int tid = threadIdx.x;
+    const int tid = vt((int)threadIdx.x);
     load_twiddles(tw, tw_g, tid);
-    double x[1][E];
+    double x[2][E];
 #pragma unroll
-    for (int k = 0; k < E; k++) x[0][k] = (double)(tid * 8 + k);
+    for (int k = 0; k < E; k++) { x[0][k] = (double)(tid * 8 + k); x[1][k] = (double)(tid + k); }
     for (int rep = 0; rep < 2; rep++) {
         STAMP(0);
-#pragma unroll
-        for (int k = 0; k < E; k++) x[0][k] = reduce(x[0][k]);
-        lds_barrier();
+        ntt_inv<2, true>(x, tw, data, tid);
         STAMP(1);
-        { TwPass t_; inv_twiddles<3>(t_, tw, tid); inv_pass<3>(x[0], t_); }
+        ntt_fwd<2>(x, tw, data, tid);
         STAMP(2);
-        x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
-        exchange_inv<2, 1>(x, data, tid);
-        STAMP(3);
-        { TwPass t_; inv_twiddles<2>(t_, tw, tid); inv_pass<2>(x[0], t_); }
-        STAMP(4);
-        x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
-        exchange_inv<1, 1>(x, data, tid);
-        STAMP(5);
-        { TwPass t_; inv_twiddles<1>(t_, tw, tid); inv_pass<1>(x[0], t_); }
-        STAMP(6);
-        x[0][0] = reduce(x[0][0]); x[0][1] = reduce(x[0][1]);
-        exchange_inv<0, 1>(x, data, tid);
-        STAMP(7);
-        { TwPass t_; inv_twiddles<0>(t_, tw, tid); inv_pass<0>(x[0], t_); }
-        STAMP(8);
 #pragma unroll
-        for (int k = 0; k < E; k++) x[0][k] = reduce(x[0][k]);
-        STAMP(9);
-        // forward
-        { TwPass t_; fwd_twiddles<0>(t_, tw, tid); fwd_pass<0>(x[0], t_); }
-        STAMP(10);
-        exchange_fwd<0, 1>(x, data, tid);
-        STAMP(11);
-        { TwPass t_; fwd_twiddles<1>(t_, tw, tid); fwd_pass<1>(x[0], t_); }
-        STAMP(12);
-        exchange_fwd<1, 1>(x, data, tid);
-        STAMP(13);
-        { TwPass t_; fwd_twiddles<2>(t_, tw, tid); fwd_pass<2>(x[0], t_); }
-        STAMP(14);
-        exchange_fwd<2, 1>(x, data, tid);
-        STAMP(15);
-        { TwPass t_; fwd_twiddles<3>(t_, tw, tid); fwd_pass<3>(x[0], t_); }
-        STAMP(16);
+        for (int k = 0; k < E; k++) { x[0][k] *= 0x1p-11; x[1][k] *= 0x1p-11; }
     }
     double acc = 0;
 #pragma unroll
-    for (int k = 0; k < E; k++) acc += x[0][k];
+    for (int k = 0; k < E; k++) acc += x[0][k] + x[1][k];
     sink[blockIdx.x * T + tid] = acc;
 }
 #endif
@@ -2519,7 +2122,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_fine(KsArgs ka) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
-    const int tid = threadIdx.x;
+    const int tid = vt((int)threadIdx.x);
     STAMPZ(0);
     TwRegs twr;
     twiddles_issue(twr, ka.tw, tid);
@@ -2615,7 +2218,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product_fine(GlweRef a, cons
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
-    const int tid = threadIdx.x;
+    const int tid = vt((int)threadIdx.x);
     TwRegs twr;
     twiddles_issue(twr, tw_g, tid);
     const int32_t* ap = at(a);
@@ -2833,7 +2436,7 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
     const int slot = bi / MEMBERS, m = bi % MEMBERS;
     const int ctg = slot * 8 + xcd;            // ciphertext (group) of this workgroup
     if (slot >= GPX || ctg >= ma.n_ct) return;
-    const int tid0 = threadIdx.x;
+    const int tid0 = vt((int)threadIdx.x);
     int tid = tid0;
     const int r = m % RS, h = m / RS;          // input digit (RS == 1: all three); output limb polynomials h * LPM + l
     double* tw = lds;
@@ -3180,7 +2783,7 @@ __global__ __launch_bounds__(T, T / 256) void k_encrypt_sk(int32_t* __restrict__
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
     double* data = lds + LDS_TW;
-    const int tid = threadIdx.x;
+    const int tid = vt((int)threadIdx.x);
     load_twiddles(tw, tw_g, tid);
     int32_t* cp = cts + (long)blockIdx.x * (S * 2 * N);
     const int32_t* pp = pt1 ? pt1 + (long)blockIdx.x * (S * N) : nullptr;

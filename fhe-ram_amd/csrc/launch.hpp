@@ -14,11 +14,11 @@ int pick_nco(const fheram_ctx* c, int gx, int gy) {
     if (c->nco != 0) return c->nco;
     return ((long)gx * gy * 2 <= c->cus) ? 1 : 2;
 }
-// gal != 0: automorphism key of Galois element gal, prepared as NTT(phi_gal(K)) (see k_prepare)
+// gal != 0: automorphism key of Galois element gal, prepared as FFT(phi_gal(K)) (see k_prepare)
 void launch_prepare(fheram_ctx* c, const int32_t* in, double* out, int npoly, int64_t gal = 0) {
     ProfScope ps(c, "prepare", npoly);
     const int ginv = gal == 0 ? 0 : galois_inv_mod(galois_mod(gal));
-    hipLaunchKernelGGL(k_prepare, dim3(npoly), dim3(T), LDS_PREPARE_BYTES, c->cur, in, out, c->d_tw, c->ninv, ginv);
+    hipLaunchKernelGGL(k_prepare, dim3((npoly + 1) / 2), dim3(T), LDS_PREPARE_BYTES, c->cur, in, out, c->d_tw, c->ninv, ginv, npoly);
 }
 // res = a (x) ggsw over a (gx, gy) grid of ciphertexts; res must not alias a
 // Limb-parallel path: 2*SK workgroups per ciphertext + a normalisation pass, chosen while even the
@@ -248,16 +248,12 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, rot_mul, rot_base);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
     for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
-    const int yf = n >= 2 ? c->chain_y : 0;   // intermediates handed over as Y = ceil(A/2): 1 ks_trace_y, 2 ks_trace_z (closed-form normalisation), 3 ks_trace_l (the same through LDS and registers)
+    const int yf = n >= 2 ? c->chain_y : 0;   // intermediates handed over as Y = ceil(A/2) through LDS and registers (ks_trace_l); 0: int32 limbs (ks_run)
     if (c->s_evk == 5) {
-        if (yf == 3) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
-        else if (yf == 2) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
-        else if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 1>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     } else {
-        if (yf == 3) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
-        else if (yf == 2) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 2>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
-        else if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 1>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }
 }

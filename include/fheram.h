@@ -326,19 +326,15 @@ int fheram_bench_chain(fheram_ctx* ctx, int kind, int batch, int n, int iters, f
 /* Device properties of the context's GPU (name, CU count) for the bench report. */
 int fheram_device_info(const fheram_ctx* ctx, char* name, size_t name_len, int* compute_units);
 
-/* ---- Self-tests of the arithmetic the kernels are built on (no reference counterpart: the reference delegates its
- * arithmetic to Poulpy's FFT64 backend, examples/fhe-ram.rs:3-7; SURVEY.md 7.3 asks for edge tests of the FP64
- * modular arithmetic against exact integers).  Host doubles in, host doubles out; the caller supplies the adversarial
- * operands and checks against exact integer arithmetic (tests/test_gpu_modarith.py).  Not on the RAM path. */
-/* out_mul[i] = mulmod(a[i], b[i]); out_mac[i] = macmod(acc[i], a[i], b[i]); out_red[i] = reduce(a[i])  (csrc/ntt_dev.hpp) */
-int fheram_selftest_modarith(fheram_ctx* ctx, int n, const double* a, const double* b, const double* acc, double* out_mul,
-                             double* out_mac, double* out_red);
-/* n_poly polynomials of N doubles through the transforms as the fused kernels call them.  dir 0: forward (natural-order
- * coefficients in; UNREDUCED transform values out, position 8*tid + k = bit-reversed order); dir 1: inverse x N (centred
- * coefficients out); dir 2: inverse without the initial reduction (inputs below 3.06 p). */
-int fheram_selftest_ntt(fheram_ctx* ctx, int dir, int n_poly, const double* in, double* out);
-/* the NTT modulus and the primitive 2N-th root of unity the twiddle table is built from */
-int fheram_selftest_constants(uint64_t* p, uint64_t* psi);
+/* ---- Self-test of the arithmetic the kernels are built on (no reference counterpart: the reference delegates its
+ * arithmetic to Poulpy's FFT64 backend, examples/fhe-ram.rs:3-7, whose contract — the FP64 round-off of a product of
+ * normalised limbs stays below 1/2, so rounding gives the exact integer — is the contract of csrc/fft_dev.hpp too).
+ * n_terms (even, <= 8) pairs of polynomials of N int32 coefficients in; out[0][N] = sum_r a_r * g_r and
+ * out[1][N] = sum_r a_r * g_{r ^ 1} (negacyclic) as RAW doubles, BEFORE the rounding the path applies, through the
+ * transforms, the prepared-operand scaling and the multiply-accumulate exactly as the fused kernels call them
+ * (singles != 0: every transform as a single instead of as a pair).  The caller compares with exact integer arithmetic
+ * (tests/test_gpu_fft.py).  Not on the RAM path. */
+int fheram_selftest_convolve(fheram_ctx* ctx, int n_terms, const int32_t* a, const int32_t* g, double* out, int singles);
 
 #ifdef __cplusplus
 }

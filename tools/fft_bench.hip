@@ -1,0 +1,141 @@
+// Measurement / self-check tool (not part of the product): the pair transforms of csrc/fft_dev.hpp.
+//   1. correctness: forward pair, pointwise products against prepared operands, inverse pair == exact negacyclic convolution
+//      (host, 128-bit integers), with the FP64 round-off before rounding reported;
+//   2. steady-state cost of a forward / inverse pair on one CU (one 512-thread workgroup per CU, as in the evaluator).
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I../fhe-ram_amd/csrc fft_bench.hip -o fft_bench
+#include "fft_dev.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <chrono>
+using namespace fk;
+
+__device__ __forceinline__ void cmac(double (&acc)[E], const double (&x)[E], const double (&g)[E]) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        acc[2 * m] = __builtin_fma(x[2 * m], g[2 * m], acc[2 * m]);
+        acc[2 * m] = __builtin_fma(-x[2 * m + 1], g[2 * m + 1], acc[2 * m]);
+        acc[2 * m + 1] = __builtin_fma(x[2 * m], g[2 * m + 1], acc[2 * m + 1]);
+        acc[2 * m + 1] = __builtin_fma(x[2 * m + 1], g[2 * m], acc[2 * m + 1]);
+    }
+}
+// out0 = sum_r a_r * g_r,  out1 = sum_r a_r * g_{R-1-r}   (R terms each), raw doubles (not rounded)
+template <bool SINGLE>
+__global__ __launch_bounds__(T) void k_conv(const int* a, const int* g, double* out, const double* tw_g, int R) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = vt((int)threadIdx.x);
+    load_twiddles(tw, tw_g, tid);
+    double acc[2][E];
+    for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) acc[b][k] = 0.0;
+    for (int r = 0; r < R; r += 2) {
+        double x[2][E], gg[2][E];
+        for (int k = 0; k < E; k++) {
+            x[0][k] = (double)a[(long)r * N + tid + T * k]; x[1][k] = (double)a[(long)(r + 1) * N + tid + T * k];
+            gg[0][k] = (double)g[(long)r * N + tid + T * k]; gg[1][k] = (double)g[(long)(r + 1) * N + tid + T * k];
+        }
+        if (SINGLE) {
+            ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
+            ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[1]), tw, data + LDS_DATA, tid);
+            ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&gg[0]), tw, data, tid);
+            ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&gg[1]), tw, data + LDS_DATA, tid);
+        } else {
+            ntt_fwd<2>(x, tw, data, tid);
+            ntt_fwd<2>(gg, tw, data, tid);
+        }
+        for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) gg[b][k] *= (1.0 / NC);
+        cmac(acc[0], x[0], gg[0]); cmac(acc[0], x[1], gg[1]);
+        cmac(acc[1], x[0], gg[1]); cmac(acc[1], x[1], gg[0]);
+    }
+    if (SINGLE) {
+        fft_inv2<false, true, false>(acc[0], acc[0], tw, data, data, tid);
+        fft_inv2<false, true, false>(acc[1], acc[1], tw, data + LDS_DATA, data + LDS_DATA, tid);
+    } else fft_inv2<true, true, false>(acc[0], acc[1], tw, data, data + LDS_DATA, tid);
+    for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) out[(long)b * N + tid + T * k] = acc[b][k];
+}
+
+// MODE 0: forward pair; 1: inverse pair; 2: inverse single; 3: forward pair + single (a key-switch's three)
+template <int MODE>
+__global__ __launch_bounds__(T, T / 256) void k_time(const double* tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = vt((int)threadIdx.x);
+    load_twiddles(tw, tw_g, tid);
+    double x[3][E];
+    for (int b = 0; b < 3; b++) for (int k = 0; k < E; k++) x[b][k] = (double)((tid * 8 + k + b) & 1023);
+    for (int r = 0; r < reps; r++) {
+        if (MODE == 0) ntt_fwd<2>(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, tid);
+        if (MODE == 1) ntt_inv<2, true>(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, tid);
+        if (MODE == 2) ntt_inv<1, true>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
+        if (MODE == 3) ntt_fwd<3>(x, tw, data, tid);
+        for (int b = 0; b < 3; b++) for (int k = 0; k < E; k++) x[b][k] *= 0.001;
+    }
+    double s = 0;
+    for (int b = 0; b < 3; b++) for (int k = 0; k < E; k++) s += x[b][k];
+    sink[blockIdx.x * T + threadIdx.x] = s;
+}
+
+static void exact_negacyclic(const int* a, const int* g, long long* c) {
+    std::vector<__int128> t(2 * N, 0);
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) t[i + j] += (__int128)a[i] * g[j];
+    for (int i = 0; i < N; i++) c[i] = (long long)(t[i] - t[i + N]);
+}
+template <typename K>
+static void timeit(K kern, const char* name, const double* tw, double* sink, int blocks, double per) {
+    const int reps = 2000;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), LDS_BYTES, 0, tw, sink, 10);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), LDS_BYTES, 0, tw, sink, reps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-52s blocks=%4d: %7.3f us per call, %7.3f us per polynomial transform per CU\n", name, blocks, ms * 1e3 / reps, ms * 1e3 / reps / per);
+}
+int main() {
+    std::vector<double> twh = make_fft_twiddles();
+    double *tw, *sink, *dout;
+    int *da, *dg;
+    const int R = 6;
+    hipMalloc(&tw, N * sizeof(double)); hipMalloc(&sink, 512 * T * sizeof(double)); hipMalloc(&dout, 2 * N * sizeof(double));
+    hipMalloc(&da, R * N * sizeof(int)); hipMalloc(&dg, R * N * sizeof(int));
+    hipMemcpy(tw, twh.data(), N * sizeof(double), hipMemcpyHostToDevice);
+    std::vector<int> a(R * N), g(R * N);
+    int bad = 0;
+    for (int pat = 0; pat < 4; pat++) {
+        srand(12345 + pat);
+        for (int i = 0; i < R * N; i++) {
+            if (pat == 0) { a[i] = (rand() % 131072) - 65536; g[i] = (rand() % 131072) - 65536; }
+            else if (pat == 1) { a[i] = (rand() & 1) ? -65536 : 65535; g[i] = (rand() & 1) ? -65536 : 65535; }
+            else if (pat == 2) { a[i] = -65536; g[i] = -65536; }
+            else { a[i] = (i % N == 0) ? 65535 : -65536; g[i] = -65536; }
+        }
+        hipMemcpy(da, a.data(), R * N * sizeof(int), hipMemcpyHostToDevice);
+        hipMemcpy(dg, g.data(), R * N * sizeof(int), hipMemcpyHostToDevice);
+        std::vector<long long> c0(N, 0), c1(N, 0), tmp(N);
+        for (int r = 0; r < R; r++) {
+            exact_negacyclic(&a[r * N], &g[r * N], tmp.data()); for (int i = 0; i < N; i++) c0[i] += tmp[i];
+            exact_negacyclic(&a[r * N], &g[(r ^ 1) * N], tmp.data()); for (int i = 0; i < N; i++) c1[i] += tmp[i];
+        }
+        for (int single = 0; single < 2; single++) {
+            if (single) hipLaunchKernelGGL(k_conv<true>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
+            else hipLaunchKernelGGL(k_conv<false>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
+            std::vector<double> o(2 * N);
+            hipMemcpy(o.data(), dout, 2 * N * sizeof(double), hipMemcpyDeviceToHost);
+            double e = 0, mx = 0;
+            for (int i = 0; i < N; i++) {
+                e = std::max(e, std::abs(o[i] - (double)c0[i])); e = std::max(e, std::abs(o[N + i] - (double)c1[i]));
+                mx = std::max(mx, std::abs((double)c0[i]));
+            }
+            printf("pattern %d %s: max |exact| = 2^%.2f, max round-off = %.3g (2^%.2f) %s\n", pat, single ? "singles" : "pair   ", log2(mx), e, log2(e + 1e-300), e < 0.25 ? "ok" : "BAD");
+            if (!(e < 0.25)) bad++;
+        }
+    }
+    timeit(k_time<0>, "forward pair", tw, sink, 256, 2);
+    timeit(k_time<1>, "inverse pair", tw, sink, 256, 2);
+    timeit(k_time<2>, "inverse single", tw, sink, 256, 1);
+    timeit(k_time<3>, "forward pair + single (3 polynomials)", tw, sink, 256, 3);
+    return bad ? 1 : 0;
+}
