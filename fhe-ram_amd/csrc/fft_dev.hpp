@@ -22,7 +22,8 @@
 //     lane bit 5 and bits 7..5 on the wave id, so that the swap partner (lane ^ 32) holds the points 256 further on.
 //     Consecutive lanes 0..31 still hold consecutive coefficients (coalesced 128-byte rows, conflict-free odd-stride LDS
 //     gathers).
-//   * a single polynomial runs as a pair with a zero partner whose LDS traffic is masked off.
+//   * a single polynomial runs on all 64 lanes too (fft_fwd1 / fft_inv1): four points per lane, each three-stage pass split
+//     around a swap round; same exchanges, same order of the results, half a pair's work.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -301,20 +302,139 @@ __device__ __forceinline__ void fft_inv2(double (&a)[E], double (&b)[E], const d
     }
 }
 
+// ---- a single polynomial on all 64 lanes -------------------------------------------------------------------------------------
+// Four complex points per thread; every three-stage pass is two stages in registers, one v_permlane32_swap round that trades
+// the lower register bit for lane bit 5, and the third stage — so the exchanges, their layouts and the order of the results are
+// those of the pair transform (a polynomial may go forward in a pair and come back alone), at half a pair's work.
+//   natural  : y[2 b10 + b9], lane bit 5 = b8     -> stages b10, b9, swap, stage b8 ->   exchange 0 (across waves)
+//   then     : y[2 b7 + b6],  lane bit 5 = b5     -> stages b7, b6,  swap, stage b5 ->   exchange 1 (in the wave)
+//   then     : y[2 b4 + b3],  lane bit 5 = b2     -> stages b4, b3,  swap, stage b2 ->   exchange 2 (in the wave)
+//   then     : y[2 b1 + b0],  lane bit 5 = b2     -> stages b1, b0
+struct XAddr1 {
+    int w, l5;
+    int x0a;   // l5 * 576 + w * 36 + ll                     + b10 * 1152 + b8 * 288
+    int x0b;   // w * 288 + l5 * 36 + ll                     + b7 * 144 + b6 * 72
+    int x1a;   // w * 288 + l5 * 72 + ll                     + b7 * 144 + b5 * 36
+    int x1b;   // w * 288 + hi3 * 36 + l5 * 4 + lo2          + b4 * 16 + b3 * 8
+    int x2a;   // (hi3 * 32 | l5 * 8 | lo2) ^ ((hi3 & 3) * 4 | l5)       ^ (b4 * 18 | b2 * 4)
+    int x2b;   // (ll * 8 | l5 * 4) ^ (ll & 15)                           ^ c
+    int h2, h3;   // heap nodes of passes 2 and 3: 64 + 8 w + hi3,  512 + 64 w + 2 ll + l5
+};
+__device__ __forceinline__ XAddr1 xaddr1(int tid) {
+    XAddr1 a;
+    const int w = (tid >> 5) & 7, ll = tid & 31, l5 = tid >> 8, hi3 = ll >> 2, lo2 = ll & 3;
+    a.w = w; a.l5 = l5;
+    a.x0a = l5 * 576 + w * 36 + ll;
+    a.x0b = w * 288 + l5 * 36 + ll;
+    a.x1a = w * 288 + l5 * 72 + ll;
+    a.x1b = w * 288 + hi3 * 36 + l5 * 4 + lo2;
+    a.x2a = w * 288 + (((hi3 * 32) | (l5 * 8) | lo2) ^ (((hi3 & 3) * 4) | l5));
+    a.x2b = w * 288 + (((ll * 8) | (l5 * 4)) ^ (ll & 15));
+    a.h2 = 64 + 8 * w + hi3;
+    a.h3 = 512 + 64 * w + 2 * ll + l5;
+    return a;
+}
+// in / out as fft_fwd2 (one polynomial)
+__device__ __forceinline__ void fft_fwd1(double (&a)[E], const double* tw_, double* buf_, int tid) {
+    const d2* tw = reinterpret_cast<const d2*>(tw_);
+    d2* buf = reinterpret_cast<d2*>(buf_);
+    const XAddr1 xa = xaddr1(tid);
+    d2 y[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { y[k].x = a[k]; y[k].y = a[k + 4]; }
+    {
+        const d2 w1 = tw[1], w2 = tw[2], w3 = tw[3], w4 = tw[4 + xa.l5], w6 = tw[6 + xa.l5];
+        bf(y[0], y[2], w1); bf(y[1], y[3], w1);
+        bf(y[0], y[1], w2); bf(y[2], y[3], w3);
+        swap32(y[0], y[1]); swap32(y[2], y[3]);
+        bf(y[0], y[1], w4); bf(y[2], y[3], w6);
+    }
+    const d2 v1 = tw[8 + xa.w], v2 = tw[16 + 2 * xa.w], v3 = tw[17 + 2 * xa.w], v4 = tw[32 + 4 * xa.w + xa.l5], v6 = tw[34 + 4 * xa.w + xa.l5];
+    lds_barrier();
+    buf[xa.x0a] = y[0]; buf[xa.x0a + 288] = y[1]; buf[xa.x0a + 1152] = y[2]; buf[xa.x0a + 1440] = y[3];
+    lds_barrier();
+    y[0] = buf[xa.x0b]; y[1] = buf[xa.x0b + 72]; y[2] = buf[xa.x0b + 144]; y[3] = buf[xa.x0b + 216];
+    bf(y[0], y[2], v1); bf(y[1], y[3], v1);
+    bf(y[0], y[1], v2); bf(y[2], y[3], v3);
+    swap32(y[0], y[1]); swap32(y[2], y[3]);
+    bf(y[0], y[1], v4); bf(y[2], y[3], v6);
+    const d2 u1 = tw[xa.h2], u2 = tw[2 * xa.h2], u3 = tw[2 * xa.h2 + 1], u4 = tw[4 * xa.h2 + xa.l5], u6 = tw[4 * xa.h2 + 2 + xa.l5];
+    buf[xa.x1a] = y[0]; buf[xa.x1a + 36] = y[1]; buf[xa.x1a + 144] = y[2]; buf[xa.x1a + 180] = y[3];
+    wave_lds_fence();
+    y[0] = buf[xa.x1b]; y[1] = buf[xa.x1b + 8]; y[2] = buf[xa.x1b + 16]; y[3] = buf[xa.x1b + 24];
+    bf(y[0], y[2], u1); bf(y[1], y[3], u1);
+    bf(y[0], y[1], u2); bf(y[2], y[3], u3);
+    swap32(y[0], y[1]); swap32(y[2], y[3]);
+    bf(y[0], y[1], u4); bf(y[2], y[3], u6);
+    const d2 t1 = tw[xa.h3], t2 = tw[2 * xa.h3], t3 = tw[2 * xa.h3 + 1];
+    buf[xa.x2a] = y[0]; buf[xa.x2a ^ 4] = y[1]; buf[xa.x2a ^ 18] = y[2]; buf[xa.x2a ^ 22] = y[3];
+    wave_lds_fence();
+    y[0] = buf[xa.x2b]; y[1] = buf[xa.x2b ^ 1]; y[2] = buf[xa.x2b ^ 2]; y[3] = buf[xa.x2b ^ 3];
+    bf(y[0], y[2], t1); bf(y[1], y[3], t1);
+    bf(y[0], y[1], t2); bf(y[2], y[3], t3);
+#pragma unroll
+    for (int m = 0; m < 4; m++) { a[2 * m] = y[m].x; a[2 * m + 1] = y[m].y; }
+}
+// in / out / FENCE as fft_inv2 (one polynomial)
+template <bool FENCE, bool ROUND = true>
+__device__ __forceinline__ void fft_inv1(double (&a)[E], const double* tw_, double* buf_, int tid) {
+    const d2* tw = reinterpret_cast<const d2*>(tw_);
+    d2* buf = reinterpret_cast<d2*>(buf_);
+    const XAddr1 xa = xaddr1(tid);
+    d2 y[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) { y[m].x = a[2 * m]; y[m].y = a[2 * m + 1]; }
+    {
+        const d2 t1 = tw[xa.h3], t2 = tw[2 * xa.h3], t3 = tw[2 * xa.h3 + 1];
+        gs(y[0], y[1], t2); gs(y[2], y[3], t3);
+        gs(y[0], y[2], t1); gs(y[1], y[3], t1);
+    }
+    const d2 u1 = tw[xa.h2], u2 = tw[2 * xa.h2], u3 = tw[2 * xa.h2 + 1], u4 = tw[4 * xa.h2 + xa.l5], u6 = tw[4 * xa.h2 + 2 + xa.l5];
+    if constexpr (FENCE) lds_barrier();
+    buf[xa.x2b] = y[0]; buf[xa.x2b ^ 1] = y[1]; buf[xa.x2b ^ 2] = y[2]; buf[xa.x2b ^ 3] = y[3];
+    wave_lds_fence();
+    y[0] = buf[xa.x2a]; y[1] = buf[xa.x2a ^ 4]; y[2] = buf[xa.x2a ^ 18]; y[3] = buf[xa.x2a ^ 22];
+    gs(y[0], y[1], u4); gs(y[2], y[3], u6);
+    swap32(y[0], y[1]); swap32(y[2], y[3]);
+    gs(y[0], y[1], u2); gs(y[2], y[3], u3);
+    gs(y[0], y[2], u1); gs(y[1], y[3], u1);
+    const d2 v1 = tw[8 + xa.w], v2 = tw[16 + 2 * xa.w], v3 = tw[17 + 2 * xa.w], v4 = tw[32 + 4 * xa.w + xa.l5], v6 = tw[34 + 4 * xa.w + xa.l5];
+    buf[xa.x1b] = y[0]; buf[xa.x1b + 8] = y[1]; buf[xa.x1b + 16] = y[2]; buf[xa.x1b + 24] = y[3];
+    wave_lds_fence();
+    y[0] = buf[xa.x1a]; y[1] = buf[xa.x1a + 36]; y[2] = buf[xa.x1a + 144]; y[3] = buf[xa.x1a + 180];
+    gs(y[0], y[1], v4); gs(y[2], y[3], v6);
+    swap32(y[0], y[1]); swap32(y[2], y[3]);
+    gs(y[0], y[1], v2); gs(y[2], y[3], v3);
+    gs(y[0], y[2], v1); gs(y[1], y[3], v1);
+    const d2 w1 = tw[1], w2 = tw[2], w3 = tw[3], w4 = tw[4 + xa.l5], w6 = tw[6 + xa.l5];
+    buf[xa.x0b] = y[0]; buf[xa.x0b + 72] = y[1]; buf[xa.x0b + 144] = y[2]; buf[xa.x0b + 216] = y[3];
+    lds_barrier();
+    y[0] = buf[xa.x0a]; y[1] = buf[xa.x0a + 288]; y[2] = buf[xa.x0a + 1152]; y[3] = buf[xa.x0a + 1440];
+    gs(y[0], y[1], w4); gs(y[2], y[3], w6);
+    swap32(y[0], y[1]); swap32(y[2], y[3]);
+    gs(y[0], y[1], w2); gs(y[2], y[3], w3);
+    gs(y[0], y[2], w1); gs(y[1], y[3], w1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if constexpr (ROUND) { a[k] = __builtin_rint(y[k].x); a[k + 4] = __builtin_rint(y[k].y); }
+        else { a[k] = y[k].x; a[k + 4] = y[k].y; }
+    }
+}
+
 // ---- the interface the kernels use (B polynomials at a time; data = B consecutive exchange buffers of LDS_DATA doubles) --------
 template <int B>
 __device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, double* data, int tid) {
     static_assert(B >= 1 && B <= BMAX, "one to three polynomials");
     if constexpr (B >= 2) fft_fwd2<true>(x[0], x[1], tw, data, data + LDS_DATA, tid);
-    if constexpr (B == 1) fft_fwd2<false>(x[0], x[0], tw, data, data, tid);
-    if constexpr (B == 3) fft_fwd2<false>(x[2], x[2], tw, data + 2 * LDS_DATA, data + 2 * LDS_DATA, tid);
+    if constexpr (B == 1) fft_fwd1(x[0], tw, data, tid);
+    if constexpr (B == 3) fft_fwd1(x[2], tw, data + 2 * LDS_DATA, tid);
 }
 // PRE is accepted for the call sites' sake (the modular transform had an initial reduction); unused.
 template <int B, bool FENCE = true, bool PRE = true>
 __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, double* data, int tid) {
     static_assert(B >= 1 && B <= 2, "one or two polynomials");
     if constexpr (B == 2) fft_inv2<true, FENCE>(x[0], x[1], tw, data, data + LDS_DATA, tid);
-    else fft_inv2<false, FENCE>(x[0], x[0], tw, data, data, tid);
+    else fft_inv1<FENCE>(x[0], tw, data, tid);
 }
 template <bool FENCE = true, bool PRE = true>
 __device__ __forceinline__ void ntt_inv2_skew(double (&x)[2][E], const double* tw, double* d0, double* d1, int tid) {

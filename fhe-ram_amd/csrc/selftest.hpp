@@ -53,8 +53,8 @@ __global__ __launch_bounds__(T) void k_selftest_convolve(const int32_t* __restri
         mac_regs(acc[1], x[0], o[1]); mac_regs(acc[1], x[1], o[0]);
     }
     if constexpr (SINGLE) {
-        fft_inv2<false, true, false>(acc[0], acc[0], tw, data, data, tid);
-        fft_inv2<false, true, false>(acc[1], acc[1], tw, data + LDS_DATA, data + LDS_DATA, tid);
+        fft_inv1<true, false>(acc[0], tw, data, tid);
+        fft_inv1<true, false>(acc[1], tw, data + LDS_DATA, tid);
     } else fft_inv2<true, true, false>(acc[0], acc[1], tw, data, data + LDS_DATA, tid);
 #pragma unroll
     for (int b = 0; b < 2; b++)

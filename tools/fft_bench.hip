@@ -20,7 +20,7 @@ __device__ __forceinline__ void cmac(double (&acc)[E], const double (&x)[E], con
     }
 }
 // out0 = sum_r a_r * g_r,  out1 = sum_r a_r * g_{R-1-r}   (R terms each), raw doubles (not rounded)
-template <bool SINGLE>
+template <int MODE>   // 0 pairs, 1 singles, 2 forward pairs + inverse singles, 3 forward singles + inverse pair
 __global__ __launch_bounds__(T) void k_conv(const int* a, const int* g, double* out, const double* tw_g, int R) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(T) void k_conv(const int* a, const int* g, double* 
             x[0][k] = (double)a[(long)r * N + tid + T * k]; x[1][k] = (double)a[(long)(r + 1) * N + tid + T * k];
             gg[0][k] = (double)g[(long)r * N + tid + T * k]; gg[1][k] = (double)g[(long)(r + 1) * N + tid + T * k];
         }
-        if (SINGLE) {
+        if (MODE == 1 || MODE == 3) {
             ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
             ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[1]), tw, data + LDS_DATA, tid);
             ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&gg[0]), tw, data, tid);
@@ -48,9 +48,9 @@ __global__ __launch_bounds__(T) void k_conv(const int* a, const int* g, double* 
         cmac(acc[0], x[0], gg[0]); cmac(acc[0], x[1], gg[1]);
         cmac(acc[1], x[0], gg[1]); cmac(acc[1], x[1], gg[0]);
     }
-    if (SINGLE) {
-        fft_inv2<false, true, false>(acc[0], acc[0], tw, data, data, tid);
-        fft_inv2<false, true, false>(acc[1], acc[1], tw, data + LDS_DATA, data + LDS_DATA, tid);
+    if (MODE == 1 || MODE == 2) {
+        fft_inv1<true, false>(acc[0], tw, data, tid);
+        fft_inv1<true, false>(acc[1], tw, data + LDS_DATA, tid);
     } else fft_inv2<true, true, false>(acc[0], acc[1], tw, data, data + LDS_DATA, tid);
     for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) out[(long)b * N + tid + T * k] = acc[b][k];
 }
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(T, T / 256) void k_time(const double* tw_g, double*
         if (MODE == 1) ntt_inv<2, true>(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, tid);
         if (MODE == 2) ntt_inv<1, true>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
         if (MODE == 3) ntt_fwd<3>(x, tw, data, tid);
+        if (MODE == 4) ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
         for (int b = 0; b < 3; b++) for (int k = 0; k < E; k++) x[b][k] *= 0.001;
     }
     double s = 0;
@@ -119,9 +120,11 @@ int main() {
             exact_negacyclic(&a[r * N], &g[r * N], tmp.data()); for (int i = 0; i < N; i++) c0[i] += tmp[i];
             exact_negacyclic(&a[r * N], &g[(r ^ 1) * N], tmp.data()); for (int i = 0; i < N; i++) c1[i] += tmp[i];
         }
-        for (int single = 0; single < 2; single++) {
-            if (single) hipLaunchKernelGGL(k_conv<true>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
-            else hipLaunchKernelGGL(k_conv<false>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
+        for (int single = 0; single < 4; single++) {
+            if (single == 1) hipLaunchKernelGGL(k_conv<1>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
+            else if (single == 2) hipLaunchKernelGGL(k_conv<2>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
+            else if (single == 3) hipLaunchKernelGGL(k_conv<3>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
+            else hipLaunchKernelGGL(k_conv<0>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
             std::vector<double> o(2 * N);
             hipMemcpy(o.data(), dout, 2 * N * sizeof(double), hipMemcpyDeviceToHost);
             double e = 0, mx = 0;
@@ -129,13 +132,14 @@ int main() {
                 e = std::max(e, std::abs(o[i] - (double)c0[i])); e = std::max(e, std::abs(o[N + i] - (double)c1[i]));
                 mx = std::max(mx, std::abs((double)c0[i]));
             }
-            printf("pattern %d %s: max |exact| = 2^%.2f, max round-off = %.3g (2^%.2f) %s\n", pat, single ? "singles" : "pair   ", log2(mx), e, log2(e + 1e-300), e < 0.25 ? "ok" : "BAD");
+            printf("pattern %d %s: max |exact| = 2^%.2f, max round-off = %.3g (2^%.2f) %s\n", pat, single == 0 ? "pairs      " : single == 1 ? "singles    " : single == 2 ? "pair/single" : "single/pair", log2(mx), e, log2(e + 1e-300), e < 0.25 ? "ok" : "BAD");
             if (!(e < 0.25)) bad++;
         }
     }
     timeit(k_time<0>, "forward pair", tw, sink, 256, 2);
     timeit(k_time<1>, "inverse pair", tw, sink, 256, 2);
     timeit(k_time<2>, "inverse single", tw, sink, 256, 1);
+    timeit(k_time<4>, "forward single", tw, sink, 256, 1);
     timeit(k_time<3>, "forward pair + single (3 polynomials)", tw, sink, 256, 3);
     return bad ? 1 : 0;
 }
