@@ -9,21 +9,22 @@
 // normalised 17-bit limbs bounded by 6 * 4096 * 2^32 < 2^47; the inverse transform's output is rounded to
 // the nearest integer, which is that integer as long as the accumulated FP64 round-off stays below 1/2 — the reference
 // backend's own contract.  Measured round-off (tests/test_gpu_fft.py, tools/fft_bench.hip): <= 2^-9 on uniformly random
-// limbs at any magnitude, 0.11 on the worst coherent pattern (every coefficient -2^16, six terms).
+// limbs at any magnitude, 0.125 on the worst coherent pattern (every coefficient -2^16, six terms).
 //
-// Decomposition (one 512-thread workgroup, 8 waves):
-//   * the unit of work is a PAIR of polynomials.  In natural order thread t holds coefficients t + 512 k (k < 8) of both,
-//     i.e. 4 complex points of each; one round of v_permlane32_swap turns that into 8 complex points of ONE polynomial
-//     (lanes 0-31: polynomial A, lanes 32-63: polynomial B), so the 11 butterfly stages run as radix-8 register passes
-//     3 + 3 + 3 + 2 with THREE LDS exchanges (one across waves, two inside a wave) — the exchange count of a radix-8
-//     transform on 4096 reals, at 6 (forward) / 8 (inverse) FP64 instructions per complex butterfly instead of 8 per
-//     modular one on twice as many points, and 4 FMAs per complex multiply-accumulate instead of 7 per modular one.
-//   * for that the "thread id" of every kernel that calls a transform is the VIRTUAL id vt() below: index bit 8 sits on
-//     lane bit 5 and bits 7..5 on the wave id, so that the swap partner (lane ^ 32) holds the points 256 further on.
-//     Consecutive lanes 0..31 still hold consecutive coefficients (coalesced 128-byte rows, conflict-free odd-stride LDS
-//     gathers).
-//   * a single polynomial runs on all 64 lanes too (fft_fwd1 / fft_inv1): four points per lane, each three-stage pass split
-//     around a swap round; same exchanges, same order of the results, half a pair's work.
+// Decomposition: one 512-thread workgroup (8 waves) per polynomial, 4 complex points (= 8 coefficients) per thread, i.e. two
+// index bits in registers.  A swap round (v_permlane32_swap / v_permlane16_swap: one instruction per register pair) trades a
+// register bit for lane bit 5 or 4, so a pass covers up to FOUR stages without touching LDS: two stages, swap with lane bit 5,
+// one stage, swap with lane bit 4, one stage.  The 11 stages are passes of 3 + 4 + 4 with TWO LDS exchanges of 32 KB between
+// them — exchange 0 across waves (one workgroup barrier in the inverse, two in the forward), exchange 1 inside the wave's
+// own region, XOR-swizzled; both sides of both are bank-conflict free with 16-byte accesses.
+// 6 (forward) / 8 (inverse) FP64 instructions per complex butterfly and 4 FMAs per complex multiply-accumulate — against 8 and
+// 7 per point for a modular transform on twice as many points, with three exchanges.
+// Several polynomials run HALF A PHASE apart in one wave (fft_fwd_skew / fft_inv_skew): the exchange of one is in flight while
+// the wave computes the next one's pass; they share twiddles (same thread, same points) and the barriers of exchange 0.
+//
+// For that the "thread id" of every kernel that calls a transform is the VIRTUAL id vt() below: index bit 8 sits on lane bit
+// 5 and bits 7..5 on the wave id, so that the first swap partner (lane ^ 32) holds the points 256 further on.  Consecutive
+// lanes 0..31 still hold consecutive coefficients (coalesced 128-byte rows, conflict-free odd-stride LDS gathers).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -63,22 +64,6 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// lanes l and l ^ 32 exchange: after the call lanes 0-31 hold (a, a of lane + 32), lanes 32-63 (b of lane - 32, b)
-__device__ __forceinline__ void swap32(double& a, double& b) {
-    unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a);
-    unsigned bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
-    auto r0 = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
-    auto r1 = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-__device__ __forceinline__ void swap32(d2& a, d2& b) {
-    double ar = a.x, ai = a.y, br = b.x, bi = b.y;
-    swap32(ar, br);
-    swap32(ai, bi);
-    a.x = ar; a.y = ai; b.x = br; b.y = bi;
-}
-
 // Cooley-Tukey butterfly: (u, v) <- (u + w v, u - w v), 6 FP64 instructions (the second output as 2u - first)
 __device__ __forceinline__ void bf(d2& u, d2& v, const d2 w) {
     double lr = __builtin_fma(w.x, v.x, u.x);
@@ -99,346 +84,243 @@ __device__ __forceinline__ void gs(d2& a, d2& b, const d2 w) {
     b.y = __builtin_fma(-dr, w.y, di * w.x);
 }
 
-// Twiddles of one register pass over the subtree rooted at heap node H: stage u (u = 0 .. ST-1) uses W[(H << u) + jb],
-// jb < 2^u.  Read as one group, ahead of the exchange that precedes the pass (LDS operations complete in order).
-template <int ST> struct TwPass { d2 w[(1 << ST) - 1]; };
-template <int ST>
-__device__ __forceinline__ void load_tw(TwPass<ST>& t, const d2* tw, int H) {
-#pragma unroll
-    for (int u = 0; u < ST; u++)
-#pragma unroll
-        for (int jb = 0; jb < (1 << u); jb++) t.w[(1 << u) - 1 + jb] = tw[(H << u) + jb];
-}
-// ST butterfly stages on the 2^ST values y[0 .. 2^ST)
-template <int ST>
-__device__ __forceinline__ void fwd_pass(d2* y, const TwPass<ST>& t) {
-    constexpr int R = 1 << ST;
-#pragma unroll
-    for (int u = 0; u < ST; u++) {
-        const int half = R >> (u + 1);
-#pragma unroll
-        for (int jb = 0; jb < (1 << u); jb++)
-#pragma unroll
-            for (int i = 0; i < half; i++) bf(y[2 * jb * half + i], y[2 * jb * half + i + half], t.w[(1 << u) - 1 + jb]);
+// ---- register <-> lane transpositions ------------------------------------------------------------------------------------------
+// lane_swap<L>(a, b): lanes l and l ^ 2^L exchange so that afterwards lanes with bit L clear hold (a, a of the partner) and lanes
+// with it set (b of the partner, b): the register index and lane bit L have traded places.
+template <int L>
+__device__ __forceinline__ void lane_swap_u32(unsigned& a, unsigned& b) {
+    if constexpr (L == 5) {
+        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r[0]; b = r[1];
+    } else {
+        static_assert(L == 4, "lane bits 5 and 4");
+        auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r[0]; b = r[1];
     }
 }
-template <int ST>
-__device__ __forceinline__ void inv_pass(d2* y, const TwPass<ST>& t) {
-    constexpr int R = 1 << ST;
-#pragma unroll
-    for (int u = ST - 1; u >= 0; u--) {
-        const int half = R >> (u + 1);
-#pragma unroll
-        for (int jb = 0; jb < (1 << u); jb++)
-#pragma unroll
-            for (int i = 0; i < half; i++) gs(y[2 * jb * half + i], y[2 * jb * half + i + half], t.w[(1 << u) - 1 + jb]);
-    }
+template <int L>
+__device__ __forceinline__ void lane_swap(double& a, double& b) {
+    unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a);
+    unsigned bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+    lane_swap_u32<L>(al, bl);
+    lane_swap_u32<L>(ah, bh);
+    a = __hiloint2double((int)ah, (int)al);
+    b = __hiloint2double((int)bh, (int)bl);
+}
+template <int L>
+__device__ __forceinline__ void lane_swap(d2& a, d2& b) {
+    double ar = a.x, ai = a.y, br = b.x, bi = b.y;
+    lane_swap<L>(ar, br);
+    lane_swap<L>(ai, bi);
+    a.x = ar; a.y = ai; b.x = br; b.y = bi;
 }
 
-// ---- LDS layouts of the three exchanges (complex units inside one polynomial's buffer of 2304) -------------------------------
-// Index bits of a complex point j (11 bits), c = the 3 bits a thread holds in registers, w = wave, ll = lane & 31:
-//   after pass 0 (bits 10..8 done):  j = c 256 + w 32 + ll          exchange 0: written there, read at  w 256 + c 32 + ll
-//   after pass 1 (bits 7..5 done) :  j = w 256 + c 32 + ll          exchange 1: written there, read at  w 256 + hi3 32 + c 4 + lo2   (ll = hi3 4 + lo2)
-//   after pass 2 (bits 4..2 done) :  j = w 256 + hi3 32 + c 4 + lo2 exchange 2: written there, read at  w 256 + ll 8 + c
-// Exchanges 0 and 1 use the padded layout j + 4 (j >> 5) (36 per 32: both sides of both are bank-conflict free with 16-byte
-// accesses: writes are served in groups of 8 consecutive lanes, reads in groups of 16); exchange 2 the XOR swizzle
-// j ^ ((j >> 3) & 15) inside the wave's own 288-slot region (a stride-8 read side has no conflict-free padding).  Wave w
-// owns [288 w, 288 w + 288) in every layout; only exchange 0 crosses waves.
+// ---- geometry -------------------------------------------------------------------------------------------------------------------
+// Index bits b10..b0 of a complex point; a hardware thread is (wave W, lane bits L5..L0); y[2 hi + lo] are its four points.
+//   natural  : y (b10, b9)  L5 = b8            W = (b7 b6 b5)   L4..L0 = b4..b0
+//              pass 0: stage b10 (hi pairs), b9 (lo pairs), swap lo <-> L5, b8 (lo pairs)
+//   exchange 0 (LDS, across waves)
+//   then     : y (b7, b6)   L5 = b5  L4 = b4   W = (b10 b9 b8)  L3..L0 = b3..b0
+//              pass 1: b7 (hi), b6 (lo), swap lo <-> L5, b5 (lo), swap hi <-> L4, b4 (hi)           now y (b4, b5), L5 = b6, L4 = b7
+//   exchange 1 (LDS, inside the wave's own 256 slots, swizzled j ^ (j >> 4))
+//   then     : y (b3, b2)   L5 = b1  L4 = b0   L3..L0 = b7 b6 b5 b4
+//              pass 2: b3 (hi), b2 (lo), swap lo <-> L5, b1 (lo), swap hi <-> L4, b0 (hi)           now y (b0, b1), L5 = b2, L4 = b3
+// The transform-domain order (what a thread holds after pass 2) is what prepared operands are stored in and the inverse expects.
+// Twiddle W[node] of the recursion (node 2^s + J: stage s, block J = the s leading index bits) is stored at twpos(node): the
+// natural position up to stage 7, and for the last three stages "transposed" (the bits a lane does not share with its
+// neighbours select a block of 128, the seven leading bits the slot inside it) so that the lanes of a wave read consecutive slots.
+__host__ __device__ constexpr int twpos(int node) {
+    int s = 0;
+    while ((2 << s) <= node) s++;
+    if (s <= 7) return node;
+    const int J = node - (1 << s), low = s - 7;
+    return (1 << s) + (J & ((1 << low) - 1)) * 128 + (J >> low);
+}
 struct XAddr {
-    int w, ll, l5;
-    int x0a;   // c * 288 + [w * 36 + ll]           exchange 0, far side
-    int x0b;   // [w * 288 + ll] + c * 36          exchange 0 near side = exchange 1 far side
-    int x1;    // [w * 288 + hi3 * 36 + lo2] + 4 c  exchange 1 near side
-    int x2a;   // w * 288 + ([hi3 * 32 | (hi3 & 3) << 2 | lo2] ^ C(c))     exchange 2 far side
-    int x2b;   // w * 288 + ([ll * 8 ^ (ll & 15)] ^ c)                      exchange 2 near side
+    int x0a;   // exchange 0, natural side : L5 * 512 + W * 32 + ll                        + hi * 1024 + lo * 256
+    int x0b;   // exchange 0, far side     : W * 256 + L5 * 32 + ll                        + hi * 128 + lo * 64
+    int x1a;   // exchange 1, after pass 1 : W * 256 + swz(L4 * 128 + L5 * 64 + (ll & 15))   ^ (hi * 17 | lo * 34)
+    int x1b;   // exchange 1, before pass 2: W * 256 + swz((ll & 15) * 16 + L5 * 2 + L4)     ^ (hi * 8 | lo * 4)
+    int l5, w;
+    int t4;    // 64 + 8 W + 4 L4 + 2 L5                 stage b4: tw[t4 + lo]
+    int p;     // 16 W + (ll & 15): the seven leading bits in pass 2;  stage b3: tw[128 + p], b2: tw[256 + hi * 128 + p],
+               // b1: tw[512 + (2 hi + L5) * 128 + p], b0: tw[1024 + (4 L4 + 2 L5 + lo) * 128 + p]
+    int t1, t0;   // 512 + L5 * 128 + p,  1024 + (4 L4 + 2 L5) * 128 + p
 };
+__device__ __forceinline__ int swz(int j) { return j ^ (j >> 4); }
+// tid = vt(threadIdx.x): W = (tid >> 5) & 7, L5 = tid >> 8, L4..L0 = tid & 31
 __device__ __forceinline__ XAddr xaddr(int tid) {
     XAddr a;
-    a.w = (tid >> 5) & 7; a.ll = tid & 31; a.l5 = tid >> 8;
-    const int hi3 = a.ll >> 2, lo2 = a.ll & 3;
-    a.x0a = a.w * 36 + a.ll;
-    a.x0b = a.w * 288 + a.ll;
-    a.x1 = a.w * 288 + hi3 * 36 + lo2;
-    a.x2a = (hi3 * 32) | ((hi3 & 3) << 2) | lo2;
-    a.x2b = (a.ll * 8) ^ (a.ll & 15);
+    const int W = (tid >> 5) & 7, ll = tid & 31, L5 = tid >> 8, L4 = ll >> 4, m4 = ll & 15;
+    a.x0a = L5 * 512 + W * 32 + ll;
+    a.x0b = W * 256 + L5 * 32 + ll;
+    a.x1a = W * 256 + swz(L4 * 128 + L5 * 64 + m4);
+    a.x1b = W * 256 + swz(m4 * 16 + L5 * 2 + L4);
+    a.l5 = L5; a.w = W;
+    a.t4 = 64 + 8 * W + 4 * L4 + 2 * L5;
+    a.p = 16 * W + m4;
+    a.t1 = 512 + L5 * 128 + a.p;
+    a.t0 = 1024 + (4 * L4 + 2 * L5) * 128 + a.p;
     return a;
 }
-constexpr int x2c(int c) { return ((c & 3) << 2) | ((c >> 2) << 4) | (c >> 1); }
-
-// ---- forward transform of a pair --------------------------------------------------------------------------------------------
-// in : a[k], b[k] = coefficient tid + T k of polynomial A / B (|.| < 2^20), tid = vt(threadIdx.x)
-// out: a[2m], a[2m+1] = (re, im) of A's transform at this thread's point m (m < 4) — the order prepared operands are stored
-//      in (k_prepare) and the inverse transform expects; likewise b.
-// PAIR = false: B is a zero polynomial (b is ignored and left alone) and only bufA is touched.
-// Starts with a workgroup barrier in front of its first LDS write (every earlier LDS read of the workgroup has been issued
-// and waited for by then), ends with reads of the wave's own region.
-template <bool PAIR>
-__device__ __forceinline__ void fft_fwd2(double (&a)[E], double (&b)[E], const double* tw_, double* bufA, double* bufB, int tid) {
-    const d2* tw = reinterpret_cast<const d2*>(tw_);
-    const XAddr xa = xaddr(tid);
-    const bool on = PAIR || xa.l5 == 0;
-    d2* buf = reinterpret_cast<d2*>((PAIR && xa.l5) ? bufB : bufA);
-    d2 y[8];
-    TwPass<3> t;
-    load_tw<3>(t, tw, 1);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        d2 p, q;
-        p.x = a[k]; p.y = a[k + 4];
-        if constexpr (PAIR) { q.x = b[k]; q.y = b[k + 4]; } else { q.x = 0.0; q.y = 0.0; }
-        swap32(p, q);
-        y[2 * k] = p; y[2 * k + 1] = q;
-    }
-    fwd_pass<3>(y, t);
-    load_tw<3>(t, tw, 8 + xa.w);
-    lds_barrier();
-    if (on) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) buf[c * 288 + xa.x0a] = y[c];
-    }
-    lds_barrier();
-    if (on) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) y[c] = buf[xa.x0b + c * 36];
-    }
-    fwd_pass<3>(y, t);
-    load_tw<3>(t, tw, 64 + xa.w * 8 + (xa.ll >> 2));
-    if (on) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) buf[xa.x0b + c * 36] = y[c];
-        wave_lds_fence();
-#pragma unroll
-        for (int c = 0; c < 8; c++) y[c] = buf[xa.x1 + 4 * c];
-    }
-    fwd_pass<3>(y, t);
-    TwPass<2> t0, t1;
-    load_tw<2>(t0, tw, 512 + (xa.w * 32 + xa.ll) * 2);
-    load_tw<2>(t1, tw, 512 + (xa.w * 32 + xa.ll) * 2 + 1);
-    if (on) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) buf[xa.w * 288 + (xa.x2a ^ x2c(c))] = y[c];
-        wave_lds_fence();
-#pragma unroll
-        for (int c = 0; c < 8; c++) y[c] = buf[xa.w * 288 + (xa.x2b ^ c)];
-    }
-    fwd_pass<2>(y, t0);
-    fwd_pass<2>(y + 4, t1);
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        d2 p = y[m], q = y[4 + m];
-        swap32(p, q);
-        a[2 * m] = p.x; a[2 * m + 1] = p.y;
-        if constexpr (PAIR) { b[2 * m] = q.x; b[2 * m + 1] = q.y; }
-    }
+// twiddles of a pass: a: first stage (hi pairs), b c: second stage (lo pairs, by hi), d e: third stage (lo pairs, by hi),
+// f g: fourth stage (hi pairs, by lo)
+struct Tw7 { d2 a, b, c, d, e, f, g; };
+struct Tw5 { d2 a, b, c, d, e; };
+__device__ __forceinline__ void tw_p0(Tw5& t, const d2* tw, const XAddr& xa) { t.a = tw[1]; t.b = tw[2]; t.c = tw[3]; t.d = tw[4 + xa.l5]; t.e = tw[6 + xa.l5]; }
+__device__ __forceinline__ void tw_p1(Tw7& t, const d2* tw, const XAddr& xa) {
+    t.a = tw[8 + xa.w]; t.b = tw[16 + 2 * xa.w]; t.c = tw[17 + 2 * xa.w]; t.d = tw[32 + 4 * xa.w + xa.l5]; t.e = tw[34 + 4 * xa.w + xa.l5];
+    t.f = tw[xa.t4]; t.g = tw[xa.t4 + 1];
 }
-
-// ---- inverse transform of a pair ---------------------------------------------------------------------------------------------
-// in : a / b as fft_fwd2 leaves them (accumulated products against prepared operands, which carry the 1/n)
-// out: a[k], b[k] = coefficient tid + T k, ROUNDED to the nearest integer (an exact integer-valued double).
-// FENCE: workgroup barrier in front of the first LDS write.  Needed when another wave may still be reading this buffer
-// across waves (the far side of exchange 0 of the previous inverse transform in the SAME buffer, or a kernel's own gathers).
-template <bool PAIR, bool FENCE, bool ROUND = true>
-__device__ __forceinline__ void fft_inv2(double (&a)[E], double (&b)[E], const double* tw_, double* bufA, double* bufB, int tid) {
-    const d2* tw = reinterpret_cast<const d2*>(tw_);
-    const XAddr xa = xaddr(tid);
-    const bool on = PAIR || xa.l5 == 0;
-    d2* buf = reinterpret_cast<d2*>((PAIR && xa.l5) ? bufB : bufA);
-    d2 y[8];
-    TwPass<2> t0, t1;
-    load_tw<2>(t0, tw, 512 + (xa.w * 32 + xa.ll) * 2);
-    load_tw<2>(t1, tw, 512 + (xa.w * 32 + xa.ll) * 2 + 1);
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        d2 p, q;
-        p.x = a[2 * m]; p.y = a[2 * m + 1];
-        if constexpr (PAIR) { q.x = b[2 * m]; q.y = b[2 * m + 1]; } else { q.x = 0.0; q.y = 0.0; }
-        swap32(p, q);
-        y[m] = p; y[4 + m] = q;
-    }
-    inv_pass<2>(y, t0);
-    inv_pass<2>(y + 4, t1);
-    TwPass<3> t;
-    load_tw<3>(t, tw, 64 + xa.w * 8 + (xa.ll >> 2));
-    if constexpr (FENCE) lds_barrier();
-    if (on) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) buf[xa.w * 288 + (xa.x2b ^ c)] = y[c];
-        wave_lds_fence();
-#pragma unroll
-        for (int c = 0; c < 8; c++) y[c] = buf[xa.w * 288 + (xa.x2a ^ x2c(c))];
-    }
-    inv_pass<3>(y, t);
-    load_tw<3>(t, tw, 8 + xa.w);
-    if (on) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) buf[xa.x1 + 4 * c] = y[c];
-        wave_lds_fence();
-#pragma unroll
-        for (int c = 0; c < 8; c++) y[c] = buf[xa.x0b + c * 36];
-    }
-    inv_pass<3>(y, t);
-    load_tw<3>(t, tw, 1);
-    if (on) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) buf[xa.x0b + c * 36] = y[c];
-    }
-    lds_barrier();
-    if (on) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) y[c] = buf[c * 288 + xa.x0a];
-    }
-    inv_pass<3>(y, t);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        d2 p = y[2 * k], q = y[2 * k + 1];
-        swap32(p, q);
-        if constexpr (ROUND) {
-            a[k] = __builtin_rint(p.x); a[k + 4] = __builtin_rint(p.y);
-            if constexpr (PAIR) { b[k] = __builtin_rint(q.x); b[k + 4] = __builtin_rint(q.y); }
-        } else {   // (round-off measurements only)
-            a[k] = p.x; a[k + 4] = p.y;
-            if constexpr (PAIR) { b[k] = q.x; b[k + 4] = q.y; }
-        }
-    }
+__device__ __forceinline__ void tw_p2(Tw7& t, const d2* tw, const XAddr& xa) {
+    t.a = tw[128 + xa.p]; t.b = tw[256 + xa.p]; t.c = tw[384 + xa.p]; t.d = tw[xa.t1]; t.e = tw[xa.t1 + 256];
+    t.f = tw[xa.t0]; t.g = tw[xa.t0 + 128];
 }
-
-// ---- a single polynomial on all 64 lanes -------------------------------------------------------------------------------------
-// Four complex points per thread; every three-stage pass is two stages in registers, one v_permlane32_swap round that trades
-// the lower register bit for lane bit 5, and the third stage — so the exchanges, their layouts and the order of the results are
-// those of the pair transform (a polynomial may go forward in a pair and come back alone), at half a pair's work.
-//   natural  : y[2 b10 + b9], lane bit 5 = b8     -> stages b10, b9, swap, stage b8 ->   exchange 0 (across waves)
-//   then     : y[2 b7 + b6],  lane bit 5 = b5     -> stages b7, b6,  swap, stage b5 ->   exchange 1 (in the wave)
-//   then     : y[2 b4 + b3],  lane bit 5 = b2     -> stages b4, b3,  swap, stage b2 ->   exchange 2 (in the wave)
-//   then     : y[2 b1 + b0],  lane bit 5 = b2     -> stages b1, b0
-struct XAddr1 {
-    int w, l5;
-    int x0a;   // l5 * 576 + w * 36 + ll                     + b10 * 1152 + b8 * 288
-    int x0b;   // w * 288 + l5 * 36 + ll                     + b7 * 144 + b6 * 72
-    int x1a;   // w * 288 + l5 * 72 + ll                     + b7 * 144 + b5 * 36
-    int x1b;   // w * 288 + hi3 * 36 + l5 * 4 + lo2          + b4 * 16 + b3 * 8
-    int x2a;   // (hi3 * 32 | l5 * 8 | lo2) ^ ((hi3 & 3) * 4 | l5)       ^ (b4 * 18 | b2 * 4)
-    int x2b;   // (ll * 8 | l5 * 4) ^ (ll & 15)                           ^ c
-    int h2, h3;   // heap nodes of passes 2 and 3: 64 + 8 w + hi3,  512 + 64 w + 2 ll + l5
-};
-__device__ __forceinline__ XAddr1 xaddr1(int tid) {
-    XAddr1 a;
-    const int w = (tid >> 5) & 7, ll = tid & 31, l5 = tid >> 8, hi3 = ll >> 2, lo2 = ll & 3;
-    a.w = w; a.l5 = l5;
-    a.x0a = l5 * 576 + w * 36 + ll;
-    a.x0b = w * 288 + l5 * 36 + ll;
-    a.x1a = w * 288 + l5 * 72 + ll;
-    a.x1b = w * 288 + hi3 * 36 + l5 * 4 + lo2;
-    a.x2a = w * 288 + (((hi3 * 32) | (l5 * 8) | lo2) ^ (((hi3 & 3) * 4) | l5));
-    a.x2b = w * 288 + (((ll * 8) | (l5 * 4)) ^ (ll & 15));
-    a.h2 = 64 + 8 * w + hi3;
-    a.h3 = 512 + 64 * w + 2 * ll + l5;
-    return a;
+__device__ __forceinline__ void f_pass3(d2 (&y)[4], const Tw5& t) {
+    bf(y[0], y[2], t.a); bf(y[1], y[3], t.a);
+    bf(y[0], y[1], t.b); bf(y[2], y[3], t.c);
+    lane_swap<5>(y[0], y[1]); lane_swap<5>(y[2], y[3]);
+    bf(y[0], y[1], t.d); bf(y[2], y[3], t.e);
 }
-// in / out as fft_fwd2 (one polynomial)
-__device__ __forceinline__ void fft_fwd1(double (&a)[E], const double* tw_, double* buf_, int tid) {
-    const d2* tw = reinterpret_cast<const d2*>(tw_);
-    d2* buf = reinterpret_cast<d2*>(buf_);
-    const XAddr1 xa = xaddr1(tid);
-    d2 y[4];
+__device__ __forceinline__ void f_pass4(d2 (&y)[4], const Tw7& t) {
+    bf(y[0], y[2], t.a); bf(y[1], y[3], t.a);
+    bf(y[0], y[1], t.b); bf(y[2], y[3], t.c);
+    lane_swap<5>(y[0], y[1]); lane_swap<5>(y[2], y[3]);
+    bf(y[0], y[1], t.d); bf(y[2], y[3], t.e);
+    lane_swap<4>(y[0], y[2]); lane_swap<4>(y[1], y[3]);
+    bf(y[0], y[2], t.f); bf(y[1], y[3], t.g);
+}
+__device__ __forceinline__ void i_pass4(d2 (&y)[4], const Tw7& t) {
+    gs(y[0], y[2], t.f); gs(y[1], y[3], t.g);
+    lane_swap<4>(y[0], y[2]); lane_swap<4>(y[1], y[3]);
+    gs(y[0], y[1], t.d); gs(y[2], y[3], t.e);
+    lane_swap<5>(y[0], y[1]); lane_swap<5>(y[2], y[3]);
+    gs(y[0], y[1], t.b); gs(y[2], y[3], t.c);
+    gs(y[0], y[2], t.a); gs(y[1], y[3], t.a);
+}
+__device__ __forceinline__ void i_pass3(d2 (&y)[4], const Tw5& t) {
+    gs(y[0], y[1], t.d); gs(y[2], y[3], t.e);
+    lane_swap<5>(y[0], y[1]); lane_swap<5>(y[2], y[3]);
+    gs(y[0], y[1], t.b); gs(y[2], y[3], t.c);
+    gs(y[0], y[2], t.a); gs(y[1], y[3], t.a);
+}
+// the two sides of the LDS exchanges
+__device__ __forceinline__ void x0a_w(const d2 (&y)[4], d2* buf, const XAddr& xa) { buf[xa.x0a] = y[0]; buf[xa.x0a + 256] = y[1]; buf[xa.x0a + 1024] = y[2]; buf[xa.x0a + 1280] = y[3]; }
+__device__ __forceinline__ void x0a_r(d2 (&y)[4], const d2* buf, const XAddr& xa) { y[0] = buf[xa.x0a]; y[1] = buf[xa.x0a + 256]; y[2] = buf[xa.x0a + 1024]; y[3] = buf[xa.x0a + 1280]; }
+__device__ __forceinline__ void x0b_w(const d2 (&y)[4], d2* buf, const XAddr& xa) { buf[xa.x0b] = y[0]; buf[xa.x0b + 64] = y[1]; buf[xa.x0b + 128] = y[2]; buf[xa.x0b + 192] = y[3]; }
+__device__ __forceinline__ void x0b_r(d2 (&y)[4], const d2* buf, const XAddr& xa) { y[0] = buf[xa.x0b]; y[1] = buf[xa.x0b + 64]; y[2] = buf[xa.x0b + 128]; y[3] = buf[xa.x0b + 192]; }
+__device__ __forceinline__ void x1a_w(const d2 (&y)[4], d2* buf, const XAddr& xa) { buf[xa.x1a] = y[0]; buf[xa.x1a ^ 34] = y[1]; buf[xa.x1a ^ 17] = y[2]; buf[xa.x1a ^ 51] = y[3]; }
+__device__ __forceinline__ void x1a_r(d2 (&y)[4], const d2* buf, const XAddr& xa) { y[0] = buf[xa.x1a]; y[1] = buf[xa.x1a ^ 34]; y[2] = buf[xa.x1a ^ 17]; y[3] = buf[xa.x1a ^ 51]; }
+__device__ __forceinline__ void x1b_w(const d2 (&y)[4], d2* buf, const XAddr& xa) { buf[xa.x1b] = y[0]; buf[xa.x1b ^ 4] = y[1]; buf[xa.x1b ^ 8] = y[2]; buf[xa.x1b ^ 12] = y[3]; }
+__device__ __forceinline__ void x1b_r(d2 (&y)[4], const d2* buf, const XAddr& xa) { y[0] = buf[xa.x1b]; y[1] = buf[xa.x1b ^ 4]; y[2] = buf[xa.x1b ^ 8]; y[3] = buf[xa.x1b ^ 12]; }
+// natural order: a[k] = coefficient tid + T k, point k' = (a[k'], a[k' + 4]); transform domain: point m = (a[2m], a[2m + 1])
+__device__ __forceinline__ void nat_in(d2 (&y)[4], const double (&a)[E]) {
 #pragma unroll
     for (int k = 0; k < 4; k++) { y[k].x = a[k]; y[k].y = a[k + 4]; }
-    {
-        const d2 w1 = tw[1], w2 = tw[2], w3 = tw[3], w4 = tw[4 + xa.l5], w6 = tw[6 + xa.l5];
-        bf(y[0], y[2], w1); bf(y[1], y[3], w1);
-        bf(y[0], y[1], w2); bf(y[2], y[3], w3);
-        swap32(y[0], y[1]); swap32(y[2], y[3]);
-        bf(y[0], y[1], w4); bf(y[2], y[3], w6);
-    }
-    const d2 v1 = tw[8 + xa.w], v2 = tw[16 + 2 * xa.w], v3 = tw[17 + 2 * xa.w], v4 = tw[32 + 4 * xa.w + xa.l5], v6 = tw[34 + 4 * xa.w + xa.l5];
-    lds_barrier();
-    buf[xa.x0a] = y[0]; buf[xa.x0a + 288] = y[1]; buf[xa.x0a + 1152] = y[2]; buf[xa.x0a + 1440] = y[3];
-    lds_barrier();
-    y[0] = buf[xa.x0b]; y[1] = buf[xa.x0b + 72]; y[2] = buf[xa.x0b + 144]; y[3] = buf[xa.x0b + 216];
-    bf(y[0], y[2], v1); bf(y[1], y[3], v1);
-    bf(y[0], y[1], v2); bf(y[2], y[3], v3);
-    swap32(y[0], y[1]); swap32(y[2], y[3]);
-    bf(y[0], y[1], v4); bf(y[2], y[3], v6);
-    const d2 u1 = tw[xa.h2], u2 = tw[2 * xa.h2], u3 = tw[2 * xa.h2 + 1], u4 = tw[4 * xa.h2 + xa.l5], u6 = tw[4 * xa.h2 + 2 + xa.l5];
-    buf[xa.x1a] = y[0]; buf[xa.x1a + 36] = y[1]; buf[xa.x1a + 144] = y[2]; buf[xa.x1a + 180] = y[3];
-    wave_lds_fence();
-    y[0] = buf[xa.x1b]; y[1] = buf[xa.x1b + 8]; y[2] = buf[xa.x1b + 16]; y[3] = buf[xa.x1b + 24];
-    bf(y[0], y[2], u1); bf(y[1], y[3], u1);
-    bf(y[0], y[1], u2); bf(y[2], y[3], u3);
-    swap32(y[0], y[1]); swap32(y[2], y[3]);
-    bf(y[0], y[1], u4); bf(y[2], y[3], u6);
-    const d2 t1 = tw[xa.h3], t2 = tw[2 * xa.h3], t3 = tw[2 * xa.h3 + 1];
-    buf[xa.x2a] = y[0]; buf[xa.x2a ^ 4] = y[1]; buf[xa.x2a ^ 18] = y[2]; buf[xa.x2a ^ 22] = y[3];
-    wave_lds_fence();
-    y[0] = buf[xa.x2b]; y[1] = buf[xa.x2b ^ 1]; y[2] = buf[xa.x2b ^ 2]; y[3] = buf[xa.x2b ^ 3];
-    bf(y[0], y[2], t1); bf(y[1], y[3], t1);
-    bf(y[0], y[1], t2); bf(y[2], y[3], t3);
-#pragma unroll
-    for (int m = 0; m < 4; m++) { a[2 * m] = y[m].x; a[2 * m + 1] = y[m].y; }
 }
-// in / out / FENCE as fft_inv2 (one polynomial)
-template <bool FENCE, bool ROUND = true>
-__device__ __forceinline__ void fft_inv1(double (&a)[E], const double* tw_, double* buf_, int tid) {
-    const d2* tw = reinterpret_cast<const d2*>(tw_);
-    d2* buf = reinterpret_cast<d2*>(buf_);
-    const XAddr1 xa = xaddr1(tid);
-    d2 y[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) { y[m].x = a[2 * m]; y[m].y = a[2 * m + 1]; }
-    {
-        const d2 t1 = tw[xa.h3], t2 = tw[2 * xa.h3], t3 = tw[2 * xa.h3 + 1];
-        gs(y[0], y[1], t2); gs(y[2], y[3], t3);
-        gs(y[0], y[2], t1); gs(y[1], y[3], t1);
-    }
-    const d2 u1 = tw[xa.h2], u2 = tw[2 * xa.h2], u3 = tw[2 * xa.h2 + 1], u4 = tw[4 * xa.h2 + xa.l5], u6 = tw[4 * xa.h2 + 2 + xa.l5];
-    if constexpr (FENCE) lds_barrier();
-    buf[xa.x2b] = y[0]; buf[xa.x2b ^ 1] = y[1]; buf[xa.x2b ^ 2] = y[2]; buf[xa.x2b ^ 3] = y[3];
-    wave_lds_fence();
-    y[0] = buf[xa.x2a]; y[1] = buf[xa.x2a ^ 4]; y[2] = buf[xa.x2a ^ 18]; y[3] = buf[xa.x2a ^ 22];
-    gs(y[0], y[1], u4); gs(y[2], y[3], u6);
-    swap32(y[0], y[1]); swap32(y[2], y[3]);
-    gs(y[0], y[1], u2); gs(y[2], y[3], u3);
-    gs(y[0], y[2], u1); gs(y[1], y[3], u1);
-    const d2 v1 = tw[8 + xa.w], v2 = tw[16 + 2 * xa.w], v3 = tw[17 + 2 * xa.w], v4 = tw[32 + 4 * xa.w + xa.l5], v6 = tw[34 + 4 * xa.w + xa.l5];
-    buf[xa.x1b] = y[0]; buf[xa.x1b + 8] = y[1]; buf[xa.x1b + 16] = y[2]; buf[xa.x1b + 24] = y[3];
-    wave_lds_fence();
-    y[0] = buf[xa.x1a]; y[1] = buf[xa.x1a + 36]; y[2] = buf[xa.x1a + 144]; y[3] = buf[xa.x1a + 180];
-    gs(y[0], y[1], v4); gs(y[2], y[3], v6);
-    swap32(y[0], y[1]); swap32(y[2], y[3]);
-    gs(y[0], y[1], v2); gs(y[2], y[3], v3);
-    gs(y[0], y[2], v1); gs(y[1], y[3], v1);
-    const d2 w1 = tw[1], w2 = tw[2], w3 = tw[3], w4 = tw[4 + xa.l5], w6 = tw[6 + xa.l5];
-    buf[xa.x0b] = y[0]; buf[xa.x0b + 72] = y[1]; buf[xa.x0b + 144] = y[2]; buf[xa.x0b + 216] = y[3];
-    lds_barrier();
-    y[0] = buf[xa.x0a]; y[1] = buf[xa.x0a + 288]; y[2] = buf[xa.x0a + 1152]; y[3] = buf[xa.x0a + 1440];
-    gs(y[0], y[1], w4); gs(y[2], y[3], w6);
-    swap32(y[0], y[1]); swap32(y[2], y[3]);
-    gs(y[0], y[1], w2); gs(y[2], y[3], w3);
-    gs(y[0], y[2], w1); gs(y[1], y[3], w1);
+template <bool ROUND = true>
+__device__ __forceinline__ void nat_out(const d2 (&y)[4], double (&a)[E]) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if constexpr (ROUND) { a[k] = __builtin_rint(y[k].x); a[k + 4] = __builtin_rint(y[k].y); }
-        else { a[k] = y[k].x; a[k + 4] = y[k].y; }
+        else { a[k] = y[k].x; a[k + 4] = y[k].y; }   // (round-off measurements only)
     }
+}
+__device__ __forceinline__ void dom_in(d2 (&y)[4], const double (&a)[E]) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) { y[m].x = a[2 * m]; y[m].y = a[2 * m + 1]; }
+}
+__device__ __forceinline__ void dom_out(const d2 (&y)[4], double (&a)[E]) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) { a[2 * m] = y[m].x; a[2 * m + 1] = y[m].y; }
+}
+
+// ---- B forward transforms (B <= 3), half a phase apart ---------------------------------------------------------------------------
+// in : x[b][k] = coefficient tid + T k of polynomial b (|.| < 2^20), tid = vt(threadIdx.x);  d[b]: its exchange buffer (NC complex slots)
+// out: x[b][2m], x[b][2m+1] = (re, im) of the transform at this thread's point m (m < 4)
+// Starts with a workgroup barrier in front of its first LDS write (every earlier LDS read of the workgroup has been issued and
+// waited for by then); ends with reads of the wave's own region.
+template <int B>
+__device__ __forceinline__ void fft_fwd_skew(double (&x)[B][E], const double* tw_, double* const (&d)[B], int tid) {
+    const d2* tw = reinterpret_cast<const d2*>(tw_);
+    const XAddr xa = xaddr(tid);
+    d2 y[B][4];
+    Tw5 t0; Tw7 t1, t2;
+    tw_p0(t0, tw, xa);
+#pragma unroll
+    for (int b = 0; b < B; b++) { nat_in(y[b], x[b]); f_pass3(y[b], t0); }
+    tw_p1(t1, tw, xa);
+    lds_barrier();
+#pragma unroll
+    for (int b = 0; b < B; b++) x0a_w(y[b], reinterpret_cast<d2*>(d[b]), xa);
+    lds_barrier();
+#pragma unroll
+    for (int b = 0; b < B; b++) x0b_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        f_pass4(y[b], t1);
+        x1a_w(y[b], reinterpret_cast<d2*>(d[b]), xa); wave_lds_fence(); x1b_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
+        if (b == 0) tw_p2(t2, tw, xa);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) { f_pass4(y[b], t2); dom_out(y[b], x[b]); }
+}
+// ---- B inverse transforms (B <= 3), half a phase apart ----------------------------------------------------------------------------
+// in : x[b] as fft_fwd_skew leaves it (accumulated products against prepared operands, which carry the 1/n)
+// out: x[b][k] = coefficient tid + T k, ROUNDED to the nearest integer (an exact integer-valued double)
+// FENCE: workgroup barrier in front of the first LDS write.  Needed when another wave may still be reading this buffer
+// across waves (the natural side of exchange 0 of the previous inverse transform in the SAME buffer, or a kernel's own gathers).
+template <int B, bool FENCE, bool ROUND = true>
+__device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw_, double* const (&d)[B], int tid) {
+    const d2* tw = reinterpret_cast<const d2*>(tw_);
+    const XAddr xa = xaddr(tid);
+    d2 y[B][4];
+    Tw7 t2, t1; Tw5 t0;
+    tw_p2(t2, tw, xa);
+#pragma unroll
+    for (int b = 0; b < B; b++) dom_in(y[b], x[b]);
+    if constexpr (FENCE) lds_barrier();
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        i_pass4(y[b], t2);
+        x1b_w(y[b], reinterpret_cast<d2*>(d[b]), xa); wave_lds_fence(); x1a_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
+        if (b == 0) tw_p1(t1, tw, xa);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        i_pass4(y[b], t1);
+        x0b_w(y[b], reinterpret_cast<d2*>(d[b]), xa);
+        if (b == 0) tw_p0(t0, tw, xa);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int b = 0; b < B; b++) x0a_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
+#pragma unroll
+    for (int b = 0; b < B; b++) { i_pass3(y[b], t0); nat_out<ROUND>(y[b], x[b]); }
 }
 
 // ---- the interface the kernels use (B polynomials at a time; data = B consecutive exchange buffers of LDS_DATA doubles) --------
 template <int B>
 __device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, double* data, int tid) {
     static_assert(B >= 1 && B <= BMAX, "one to three polynomials");
-    if constexpr (B >= 2) fft_fwd2<true>(x[0], x[1], tw, data, data + LDS_DATA, tid);
-    if constexpr (B == 1) fft_fwd1(x[0], tw, data, tid);
-    if constexpr (B == 3) fft_fwd1(x[2], tw, data + 2 * LDS_DATA, tid);
+    if constexpr (B == 1) { double* const d[1] = {data}; fft_fwd_skew<1>(x, tw, d, tid); }
+    if constexpr (B == 2) { double* const d[2] = {data, data + LDS_DATA}; fft_fwd_skew<2>(x, tw, d, tid); }
+    if constexpr (B == 3) { double* const d[3] = {data, data + LDS_DATA, data + 2 * LDS_DATA}; fft_fwd_skew<3>(x, tw, d, tid); }
 }
 // PRE is accepted for the call sites' sake (the modular transform had an initial reduction); unused.
 template <int B, bool FENCE = true, bool PRE = true>
 __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, double* data, int tid) {
     static_assert(B >= 1 && B <= 2, "one or two polynomials");
-    if constexpr (B == 2) fft_inv2<true, FENCE>(x[0], x[1], tw, data, data + LDS_DATA, tid);
-    else fft_inv1<FENCE>(x[0], tw, data, tid);
+    if constexpr (B == 1) { double* const d[1] = {data}; fft_inv_skew<1, FENCE>(x, tw, d, tid); }
+    else { double* const d[2] = {data, data + LDS_DATA}; fft_inv_skew<2, FENCE>(x, tw, d, tid); }
 }
 template <bool FENCE = true, bool PRE = true>
 __device__ __forceinline__ void ntt_inv2_skew(double (&x)[2][E], const double* tw, double* d0, double* d1, int tid) {
-    fft_inv2<true, FENCE>(x[0], x[1], tw, d0, d1, tid);
+    double* const d[2] = {d0, d1};
+    fft_inv_skew<2, FENCE>(x, tw, d, tid);
 }
 __device__ __forceinline__ void ntt_fwd3_skew(double (&x)[3][E], const double* tw, double* data, int tid) { ntt_fwd<3>(x, tw, data, tid); }
 
@@ -510,14 +392,14 @@ __device__ __forceinline__ void rsh1_coeff(const int (&x)[S], int (&y)[S]) {
 #include <cmath>
 #include <vector>
 namespace fk {
-inline std::vector<double> make_fft_twiddles() {
+inline std::vector<double> make_fft_twiddles() {   // in the device layout: node h at complex position twpos(h)
     std::vector<double> tw(N, 0.0);
     std::vector<long double> a(NC, 0.0L);   // angle / pi: dyadic rationals with at most 13 fractional bits, exact
     a[1] = 0.25L;
     const long double pi = 3.14159265358979323846264338327950288L;
     for (int h = 1; h < NC; h++) {
-        tw[2 * h] = (double)cosl(pi * a[h]);
-        tw[2 * h + 1] = (double)sinl(pi * a[h]);
+        tw[2 * twpos(h)] = (double)cosl(pi * a[h]);
+        tw[2 * twpos(h) + 1] = (double)sinl(pi * a[h]);
         if (2 * h < NC) { a[2 * h] = a[h] / 2; a[2 * h + 1] = a[h] / 2 + 0.5L; }
     }
     return tw;

@@ -11,7 +11,7 @@
 namespace fk {
 
 // out[0] = sum_r a_r * g_r,  out[1] = sum_r a_r * g_{r ^ 1}   (negacyclic, R terms, R even), raw doubles.
-// SINGLE: every transform runs as a single (zero partner) instead of as a pair.
+// SINGLE: every transform runs on its own instead of two at a time, half a phase apart.
 template <bool SINGLE>
 __global__ __launch_bounds__(T) void k_selftest_convolve(const int32_t* __restrict__ a, const int32_t* __restrict__ g, double* __restrict__ out,
                                                          const double* __restrict__ tw_g, double ninv, int R) {
@@ -53,9 +53,14 @@ __global__ __launch_bounds__(T) void k_selftest_convolve(const int32_t* __restri
         mac_regs(acc[1], x[0], o[1]); mac_regs(acc[1], x[1], o[0]);
     }
     if constexpr (SINGLE) {
-        fft_inv1<true, false>(acc[0], tw, data, tid);
-        fft_inv1<true, false>(acc[1], tw, data + LDS_DATA, tid);
-    } else fft_inv2<true, true, false>(acc[0], acc[1], tw, data, data + LDS_DATA, tid);
+        double* const d0[1] = {data};
+        double* const d1[1] = {data + LDS_DATA};
+        fft_inv_skew<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, d0, tid);
+        fft_inv_skew<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[1]), tw, d1, tid);
+    } else {
+        double* const d[2] = {data, data + LDS_DATA};
+        fft_inv_skew<2, true, false>(acc, tw, d, tid);
+    }
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll

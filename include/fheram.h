@@ -332,7 +332,7 @@ int fheram_device_info(const fheram_ctx* ctx, char* name, size_t name_len, int* 
  * n_terms (even, <= 8) pairs of polynomials of N int32 coefficients in; out[0][N] = sum_r a_r * g_r and
  * out[1][N] = sum_r a_r * g_{r ^ 1} (negacyclic) as RAW doubles, BEFORE the rounding the path applies, through the
  * transforms, the prepared-operand scaling and the multiply-accumulate exactly as the fused kernels call them
- * (singles != 0: every transform as a single instead of as a pair).  The caller compares with exact integer arithmetic
+ * (singles != 0: every transform on its own instead of two at a time).  The caller compares with exact integer arithmetic
  * (tests/test_gpu_fft.py).  Not on the RAM path. */
 int fheram_selftest_convolve(fheram_ctx* ctx, int n_terms, const int32_t* a, const int32_t* g, double* out, int singles);
 

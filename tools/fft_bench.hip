@@ -1,13 +1,12 @@
-// Measurement / self-check tool (not part of the product): the pair transforms of csrc/fft_dev.hpp.
-//   1. correctness: forward pair, pointwise products against prepared operands, inverse pair == exact negacyclic convolution
-//      (host, 128-bit integers), with the FP64 round-off before rounding reported;
-//   2. steady-state cost of a forward / inverse pair on one CU (one 512-thread workgroup per CU, as in the evaluator).
+// Measurement / self-check tool (not part of the product): the transforms of csrc/fft_dev.hpp.
+//   1. correctness: forward transforms, pointwise products against prepared operands, inverse transforms == exact negacyclic
+//      convolution (host, 128-bit integers), with the FP64 round-off before rounding reported;
+//   2. steady-state cost of forward / inverse transforms on one CU (one 512-thread workgroup per CU, as in the evaluator).
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I../fhe-ram_amd/csrc fft_bench.hip -o fft_bench
 #include "fft_dev.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include <chrono>
 using namespace fk;
 
 __device__ __forceinline__ void cmac(double (&acc)[E], const double (&x)[E], const double (&g)[E]) {
@@ -19,8 +18,8 @@ __device__ __forceinline__ void cmac(double (&acc)[E], const double (&x)[E], con
         acc[2 * m + 1] = __builtin_fma(x[2 * m + 1], g[2 * m], acc[2 * m + 1]);
     }
 }
-// out0 = sum_r a_r * g_r,  out1 = sum_r a_r * g_{R-1-r}   (R terms each), raw doubles (not rounded)
-template <int MODE>   // 0 pairs, 1 singles, 2 forward pairs + inverse singles, 3 forward singles + inverse pair
+// out0 = sum_r a_r * g_r,  out1 = sum_r a_r * g_{r^1}   (R terms each), raw doubles (not rounded)
+template <int MODE>   // 0: two at a time, 1: one at a time
 __global__ __launch_bounds__(T) void k_conv(const int* a, const int* g, double* out, const double* tw_g, int R) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* tw = lds;
@@ -35,7 +34,7 @@ __global__ __launch_bounds__(T) void k_conv(const int* a, const int* g, double* 
             x[0][k] = (double)a[(long)r * N + tid + T * k]; x[1][k] = (double)a[(long)(r + 1) * N + tid + T * k];
             gg[0][k] = (double)g[(long)r * N + tid + T * k]; gg[1][k] = (double)g[(long)(r + 1) * N + tid + T * k];
         }
-        if (MODE == 1 || MODE == 3) {
+        if (MODE == 1) {
             ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
             ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[1]), tw, data + LDS_DATA, tid);
             ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&gg[0]), tw, data, tid);
@@ -48,14 +47,16 @@ __global__ __launch_bounds__(T) void k_conv(const int* a, const int* g, double* 
         cmac(acc[0], x[0], gg[0]); cmac(acc[0], x[1], gg[1]);
         cmac(acc[1], x[0], gg[1]); cmac(acc[1], x[1], gg[0]);
     }
-    if (MODE == 1 || MODE == 2) {
-        fft_inv1<true, false>(acc[0], tw, data, tid);
-        fft_inv1<true, false>(acc[1], tw, data + LDS_DATA, tid);
-    } else fft_inv2<true, true, false>(acc[0], acc[1], tw, data, data + LDS_DATA, tid);
+    if (MODE == 1) {
+        double* const d0[1] = {data};
+        double* const d1[1] = {data + LDS_DATA};
+        fft_inv_skew<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, d0, tid);
+        fft_inv_skew<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[1]), tw, d1, tid);
+    } else { double* const d[2] = {data, data + LDS_DATA}; fft_inv_skew<2, true, false>(acc, tw, d, tid); }
     for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) out[(long)b * N + tid + T * k] = acc[b][k];
 }
 
-// MODE 0: forward pair; 1: inverse pair; 2: inverse single; 3: forward pair + single (a key-switch's three)
+// MODE: F1/F2/F3 forward 1..3, I1/I2/I3 inverse 1..3
 template <int MODE>
 __global__ __launch_bounds__(T, T / 256) void k_time(const double* tw_g, double* sink, int reps) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -65,12 +66,14 @@ __global__ __launch_bounds__(T, T / 256) void k_time(const double* tw_g, double*
     load_twiddles(tw, tw_g, tid);
     double x[3][E];
     for (int b = 0; b < 3; b++) for (int k = 0; k < E; k++) x[b][k] = (double)((tid * 8 + k + b) & 1023);
+    double* const d3[3] = {data, data + LDS_DATA, data + 2 * LDS_DATA};
     for (int r = 0; r < reps; r++) {
-        if (MODE == 0) ntt_fwd<2>(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, tid);
-        if (MODE == 1) ntt_inv<2, true>(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, tid);
-        if (MODE == 2) ntt_inv<1, true>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
+        if (MODE == 1) ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
+        if (MODE == 2) ntt_fwd<2>(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, tid);
         if (MODE == 3) ntt_fwd<3>(x, tw, data, tid);
-        if (MODE == 4) ntt_fwd<1>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
+        if (MODE == 11) ntt_inv<1, true>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
+        if (MODE == 12) ntt_inv<2, true>(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, tid);
+        if (MODE == 13) fft_inv_skew<3, true>(x, tw, d3, tid);
         for (int b = 0; b < 3; b++) for (int k = 0; k < E; k++) x[b][k] *= 0.001;
     }
     double s = 0;
@@ -93,7 +96,7 @@ static void timeit(K kern, const char* name, const double* tw, double* sink, int
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), LDS_BYTES, 0, tw, sink, reps);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("%-52s blocks=%4d: %7.3f us per call, %7.3f us per polynomial transform per CU\n", name, blocks, ms * 1e3 / reps, ms * 1e3 / reps / per);
+    printf("%-40s blocks=%4d: %7.3f us per call, %7.3f us per polynomial transform per CU\n", name, blocks, ms * 1e3 / reps, ms * 1e3 / reps / per);
 }
 int main() {
     std::vector<double> twh = make_fft_twiddles();
@@ -120,10 +123,8 @@ int main() {
             exact_negacyclic(&a[r * N], &g[r * N], tmp.data()); for (int i = 0; i < N; i++) c0[i] += tmp[i];
             exact_negacyclic(&a[r * N], &g[(r ^ 1) * N], tmp.data()); for (int i = 0; i < N; i++) c1[i] += tmp[i];
         }
-        for (int single = 0; single < 4; single++) {
-            if (single == 1) hipLaunchKernelGGL(k_conv<1>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
-            else if (single == 2) hipLaunchKernelGGL(k_conv<2>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
-            else if (single == 3) hipLaunchKernelGGL(k_conv<3>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
+        for (int mode = 0; mode < 2; mode++) {
+            if (mode == 1) hipLaunchKernelGGL(k_conv<1>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
             else hipLaunchKernelGGL(k_conv<0>, dim3(1), dim3(T), LDS_BYTES, 0, da, dg, dout, tw, R);
             std::vector<double> o(2 * N);
             hipMemcpy(o.data(), dout, 2 * N * sizeof(double), hipMemcpyDeviceToHost);
@@ -132,14 +133,15 @@ int main() {
                 e = std::max(e, std::abs(o[i] - (double)c0[i])); e = std::max(e, std::abs(o[N + i] - (double)c1[i]));
                 mx = std::max(mx, std::abs((double)c0[i]));
             }
-            printf("pattern %d %s: max |exact| = 2^%.2f, max round-off = %.3g (2^%.2f) %s\n", pat, single == 0 ? "pairs      " : single == 1 ? "singles    " : single == 2 ? "pair/single" : "single/pair", log2(mx), e, log2(e + 1e-300), e < 0.25 ? "ok" : "BAD");
+            printf("pattern %d %s: max |exact| = 2^%.2f, max round-off = %.3g (2^%.2f) %s\n", pat, mode == 0 ? "two at a time" : "one at a time", log2(mx), e, log2(e + 1e-300), e < 0.25 ? "ok" : "BAD");
             if (!(e < 0.25)) bad++;
         }
     }
-    timeit(k_time<0>, "forward pair", tw, sink, 256, 2);
-    timeit(k_time<1>, "inverse pair", tw, sink, 256, 2);
-    timeit(k_time<2>, "inverse single", tw, sink, 256, 1);
-    timeit(k_time<4>, "forward single", tw, sink, 256, 1);
-    timeit(k_time<3>, "forward pair + single (3 polynomials)", tw, sink, 256, 3);
+    timeit(k_time<1>, "forward, 1", tw, sink, 256, 1);
+    timeit(k_time<2>, "forward, 2 half a phase apart", tw, sink, 256, 2);
+    timeit(k_time<3>, "forward, 3 half a phase apart", tw, sink, 256, 3);
+    timeit(k_time<11>, "inverse, 1", tw, sink, 256, 1);
+    timeit(k_time<12>, "inverse, 2 half a phase apart", tw, sink, 256, 2);
+    timeit(k_time<13>, "inverse, 3 half a phase apart", tw, sink, 256, 3);
     return bad ? 1 : 0;
 }
