@@ -84,6 +84,26 @@ __device__ __forceinline__ void gs(d2& a, d2& b, const d2 w) {
     b.y = __builtin_fma(-dr, w.y, di * w.x);
 }
 
+// the same two with the twiddle i w: the twiddles of the two blocks a stage splits one block into are W[2h] and W[2h + 1] =
+// i W[2h] (their angles differ by pi / 2), so only the first is read
+__device__ __forceinline__ void bf_i(d2& u, d2& v, const d2 w) {
+    double lr = __builtin_fma(-w.y, v.x, u.x);
+    lr = __builtin_fma(-w.x, v.y, lr);
+    double li = __builtin_fma(-w.y, v.y, u.y);
+    li = __builtin_fma(w.x, v.x, li);
+    v.x = __builtin_fma(2.0, u.x, -lr);
+    v.y = __builtin_fma(2.0, u.y, -li);
+    u.x = lr;
+    u.y = li;
+}
+__device__ __forceinline__ void gs_i(d2& a, d2& b, const d2 w) {
+    const double dr = a.x - b.x, di = a.y - b.y;
+    a.x = a.x + b.x;
+    a.y = a.y + b.y;
+    b.x = __builtin_fma(di, w.x, dr * -w.y);
+    b.y = __builtin_fma(-dr, w.x, di * -w.y);
+}
+
 // ---- register <-> lane transpositions ------------------------------------------------------------------------------------------
 // lane_swap<L>(a, b): lanes l and l ^ 2^L exchange so that afterwards lanes with bit L clear hold (a, a of the partner) and lanes
 // with it set (b of the partner, b): the register index and lane bit L have traded places.
@@ -163,46 +183,52 @@ __device__ __forceinline__ XAddr xaddr(int tid) {
     a.t0 = 1024 + (4 * L4 + 2 * L5) * 128 + a.p;
     return a;
 }
-// twiddles of a pass: a: first stage (hi pairs), b c: second stage (lo pairs, by hi), d e: third stage (lo pairs, by hi),
-// f g: fourth stage (hi pairs, by lo)
-struct Tw7 { d2 a, b, c, d, e, f, g; };
-struct Tw5 { d2 a, b, c, d, e; };
-__device__ __forceinline__ void tw_p0(Tw5& t, const d2* tw, const XAddr& xa) { t.a = tw[1]; t.b = tw[2]; t.c = tw[3]; t.d = tw[4 + xa.l5]; t.e = tw[6 + xa.l5]; }
+// twiddles of a pass: a: first stage (hi pairs); b: second stage (lo pairs of hi = 0; hi = 1 uses i b); d e: third stage (lo pairs,
+// by hi); f: fourth stage (hi pairs of lo = 0; lo = 1 uses i f).  Pass 0's a and b are the constants W[1], W[2].
+struct Tw7 { d2 a, b, d, e, f; };
+struct Tw5 { d2 d, e; };
+constexpr double W1_RE = 0.70710678118654752440, W1_IM = 0.70710678118654752440;   // exp(i pi / 4)
+constexpr double W2_RE = 0.92387953251128675613, W2_IM = 0.38268343236508977173;   // exp(i pi / 8)
+__device__ __forceinline__ void tw_p0(Tw5& t, const d2* tw, const XAddr& xa) { t.d = tw[4 + xa.l5]; t.e = tw[6 + xa.l5]; }
 __device__ __forceinline__ void tw_p1(Tw7& t, const d2* tw, const XAddr& xa) {
-    t.a = tw[8 + xa.w]; t.b = tw[16 + 2 * xa.w]; t.c = tw[17 + 2 * xa.w]; t.d = tw[32 + 4 * xa.w + xa.l5]; t.e = tw[34 + 4 * xa.w + xa.l5];
-    t.f = tw[xa.t4]; t.g = tw[xa.t4 + 1];
+    t.a = tw[8 + xa.w]; t.b = tw[16 + 2 * xa.w]; t.d = tw[32 + 4 * xa.w + xa.l5]; t.e = tw[34 + 4 * xa.w + xa.l5];
+    t.f = tw[xa.t4];
 }
 __device__ __forceinline__ void tw_p2(Tw7& t, const d2* tw, const XAddr& xa) {
-    t.a = tw[128 + xa.p]; t.b = tw[256 + xa.p]; t.c = tw[384 + xa.p]; t.d = tw[xa.t1]; t.e = tw[xa.t1 + 256];
-    t.f = tw[xa.t0]; t.g = tw[xa.t0 + 128];
+    t.a = tw[128 + xa.p]; t.b = tw[256 + xa.p]; t.d = tw[xa.t1]; t.e = tw[xa.t1 + 256];
+    t.f = tw[xa.t0];
 }
 __device__ __forceinline__ void f_pass3(d2 (&y)[4], const Tw5& t) {
-    bf(y[0], y[2], t.a); bf(y[1], y[3], t.a);
-    bf(y[0], y[1], t.b); bf(y[2], y[3], t.c);
+    d2 w1, w2;
+    w1.x = W1_RE; w1.y = W1_IM; w2.x = W2_RE; w2.y = W2_IM;
+    bf(y[0], y[2], w1); bf(y[1], y[3], w1);
+    bf(y[0], y[1], w2); bf_i(y[2], y[3], w2);
     lane_swap<5>(y[0], y[1]); lane_swap<5>(y[2], y[3]);
     bf(y[0], y[1], t.d); bf(y[2], y[3], t.e);
 }
 __device__ __forceinline__ void f_pass4(d2 (&y)[4], const Tw7& t) {
     bf(y[0], y[2], t.a); bf(y[1], y[3], t.a);
-    bf(y[0], y[1], t.b); bf(y[2], y[3], t.c);
+    bf(y[0], y[1], t.b); bf_i(y[2], y[3], t.b);
     lane_swap<5>(y[0], y[1]); lane_swap<5>(y[2], y[3]);
     bf(y[0], y[1], t.d); bf(y[2], y[3], t.e);
     lane_swap<4>(y[0], y[2]); lane_swap<4>(y[1], y[3]);
-    bf(y[0], y[2], t.f); bf(y[1], y[3], t.g);
+    bf(y[0], y[2], t.f); bf_i(y[1], y[3], t.f);
 }
 __device__ __forceinline__ void i_pass4(d2 (&y)[4], const Tw7& t) {
-    gs(y[0], y[2], t.f); gs(y[1], y[3], t.g);
+    gs(y[0], y[2], t.f); gs_i(y[1], y[3], t.f);
     lane_swap<4>(y[0], y[2]); lane_swap<4>(y[1], y[3]);
     gs(y[0], y[1], t.d); gs(y[2], y[3], t.e);
     lane_swap<5>(y[0], y[1]); lane_swap<5>(y[2], y[3]);
-    gs(y[0], y[1], t.b); gs(y[2], y[3], t.c);
+    gs(y[0], y[1], t.b); gs_i(y[2], y[3], t.b);
     gs(y[0], y[2], t.a); gs(y[1], y[3], t.a);
 }
 __device__ __forceinline__ void i_pass3(d2 (&y)[4], const Tw5& t) {
+    d2 w1, w2;
+    w1.x = W1_RE; w1.y = W1_IM; w2.x = W2_RE; w2.y = W2_IM;
     gs(y[0], y[1], t.d); gs(y[2], y[3], t.e);
     lane_swap<5>(y[0], y[1]); lane_swap<5>(y[2], y[3]);
-    gs(y[0], y[1], t.b); gs(y[2], y[3], t.c);
-    gs(y[0], y[2], t.a); gs(y[1], y[3], t.a);
+    gs(y[0], y[1], w2); gs_i(y[2], y[3], w2);
+    gs(y[0], y[2], w1); gs(y[1], y[3], w1);
 }
 // the two sides of the LDS exchanges
 __device__ __forceinline__ void x0a_w(const d2 (&y)[4], d2* buf, const XAddr& xa) { buf[xa.x0a] = y[0]; buf[xa.x0a + 256] = y[1]; buf[xa.x0a + 1024] = y[2]; buf[xa.x0a + 1280] = y[3]; }

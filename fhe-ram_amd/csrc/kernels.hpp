@@ -1129,6 +1129,13 @@ __device__ __forceinline__ void fold_limb(double (&od)[E], double (&ec)[E], cons
         for (int k = 0; k < E; k++) od[k] = __builtin_fma(cmod17(acc[k]), TWO_2B, od[k]);
     }
 }
+// for 4 limbs the extra carry lives inside the call for limb 3: no state between limbs (16 registers that stay free)
+template <int SK>
+__device__ __forceinline__ void fold_limb4(double (&od)[E], const double (&acc)[E], int j) {
+    static_assert(SK == 4, "four limbs");
+    double ec[E];
+    fold_limb<SK>(od, ec, acc, j);
+}
 #ifndef FK_Z_SKEW_ODD
 #define FK_Z_SKEW_ODD 0   // ks_trace_l, 5-limb keys: the skewed pair of inverse transforms (six spilled registers with it, none without)
 #endif
@@ -1322,15 +1329,15 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
             if (two) {
                 ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                fold_limb<SK>(od, ec, acc[0], j);
-                fold_limb<SK>(od, ec, acc[1], j - 1);
+                if constexpr (SK == 4) { fold_limb4<SK>(od, acc[0], j); fold_limb4<SK>(od, acc[1], j - 1); }
+                else { fold_limb<SK>(od, ec, acc[0], j); fold_limb<SK>(od, ec, acc[1], j - 1); }
             } else {
                 ntt_inv<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                fold_limb<SK>(od, ec, acc[0], j);
+                if constexpr (SK == 4) fold_limb4<SK>(od, acc[0], j); else fold_limb<SK>(od, ec, acc[0], j);
             }
-            // the next limbs' operands: their fetch runs under the first products (requested in FRONT of the fold, the compiler does not
-            // come back: clang 22 of ROCm 7.2 loops forever on that variant)
+            // the next limbs' operands: their fetch runs under the first products (requested in front of the inverse transforms: 52-85 spilled
+            // registers, 27.0 against 25.3 us per step, profiles/r05_experiments.txt)
             if (j >= 2) fetch(j - 2, co, 0, SX);
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         }
@@ -1458,7 +1465,7 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
             fetch1(0);
             fetch1(1);
             __builtin_amdgcn_sched_barrier(0);
-            fold_limb<SG>(od, ec, acc[0], j);
+            if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
             __builtin_amdgcn_sched_barrier(0);
             fetch1(2);
             YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
