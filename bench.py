@@ -41,8 +41,31 @@ ATK_I64 = 3 * 4 * 2 * N * 8         # 786 432 B
 EVK5_I64 = 4 * 5 * 2 * N * 8        # 1 310 720 B
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TINSTR = 39.3        # 78.6 TFLOP/s vector FP64 = 39.3 T FMA-class instr/s
-FP64_PER_KS = 11 * 24576 * 8 + 24 * 4096 * 7    # trace / packer key-switch: 11 transforms x 24576 butterflies x 8 + 24 x 4096 MACs x 7
-FP64_PER_EP = 14 * 24576 * 8 + 48 * 4096 * 7    # external product: 14 transforms, 48 polynomial MACs
+# FP64 VALU instructions of the shipped arithmetic (csrc/fft_dev.hpp: negacyclic FFT64 on N/2 = 2048 complex points): a forward
+# butterfly is 6 FMA-class instructions, an inverse one 8, the rounding of an inverse transform's output 1 per coefficient, a
+# complex multiply-accumulate against a prepared operand 4
+FP64_FWD = 11 * 1024 * 6
+FP64_INV = 11 * 1024 * 8 + 4096
+FP64_MAC = 2048 * 4
+
+
+def fp64_per_keyswitch(s_evk):
+    """trace / packer key-switch with an s_evk-limb key: 3 forward, 2 s_evk inverse transforms, 3 * 2 s_evk polynomial MACs"""
+    return 3 * FP64_FWD + 2 * s_evk * FP64_INV + 3 * 2 * s_evk * FP64_MAC
+
+
+FP64_PER_KS = fp64_per_keyswitch(4)
+FP64_PER_EP = 6 * FP64_FWD + 8 * FP64_INV + 48 * FP64_MAC     # external product: 6 forward, 8 inverse transforms, 48 polynomial MACs
+# round 4's arithmetic (48-bit prime in FP64: 8 instructions per modular butterfly on 4096 points, 7 per MAC), for comparison only
+R04_FP64_PER_KS = 11 * 24576 * 8 + 24 * 4096 * 7
+R04_FP64_PER_EP = 14 * 24576 * 8 + 48 * 4096 * 7
+# SURVEY.md 8(d)'s own unit: "modmuls" (a butterfly of an N-point transform = 1, N/2 log2 N = 24 576 per transform; a pointwise MAC
+# = 4096 per polynomial pair): EP = 14 transforms + 48 MACs, trace / pack key-switch = (3 + 2 s) transforms + 6 s MACs
+MODMUL_PER_EP = 14 * 24576 + 48 * 4096
+
+
+def modmul_per_keyswitch(s_evk):
+    return (3 + 2 * s_evk) * 24576 + 6 * s_evk * 4096
 
 
 def synth(rng, shape):
@@ -78,16 +101,27 @@ def algorithmic_bytes(max_addr, ws, n_digits, atk_i64=ATK_I64):
     return read, rpw, write
 
 
-PMC_PROFILE = "profiles/r04_pmc_hbm_traffic.json"
+PMC_PROFILE = "profiles/r05_pmc_hbm_traffic.json"
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per launch of the dominant kernel shape (batch-256 fused trace step) from the committed
-    PMC profile of this command (tools/pmc_summary.py; None if absent)."""
+def pmc_profile():
     path = os.path.join(ROOT, PMC_PROFILE)
-    if not os.path.exists(path):
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM-side bytes per launch (read + written) of the kernel whose name starts with `kernel_prefix`, from the committed PMC
+    profile of this command (tools/pmc_hbm.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE calibrated);
+    None if absent"""
+    prof = pmc_profile()
+    if not prof:
         return None
-    return json.load(open(path)).get("dominant_kernel", {}).get("hbm_bytes_per_launch")
+    best = None
+    for name, e in prof.get("kernels", {}).items():
+        if name.startswith(kernel_prefix) and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e:
+            if best is None or e["launches"] > best["launches"]:
+                best = e
+    return None if best is None else best["read_bytes_per_launch"] + best["write_bytes_per_launch"]
 
 
 def make_inputs(p, ws, s_evk, n_digits, rows_local, seed_keys=1234, seed_rows=4321):
@@ -367,7 +401,7 @@ def main():
     crypto = {"k_glwe_pt": 9, "k_evk_trace": 85} if args.params == "readme" else {}
     s_evk = 5 if args.params == "readme" else 4          # limbs of a trace / packing key
     atk_i64 = 3 * s_evk * 2 * N * 8
-    fp64_per_ks = (3 + 2 * s_evk) * 24576 * 8 + 3 * 2 * s_evk * 4096 * 7
+    fp64_per_ks = fp64_per_keyswitch(s_evk)
     sharded = mode == "sharded"
     strong = sharded and args.total_log_max_addr is not None
     if strong:
@@ -550,7 +584,7 @@ def main():
             f"value(N) / value(1) = T(1) / T(N) is the weak-scaling efficiency)" if weight > 1 else ""),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "mode": mode, "vs_baseline": None, "dtype": "f64",
-        "arithmetic": "exact integers mod 2^48+57345 carried in FP64 (error-free products); int32 limbs in HBM",
+        "arithmetic": "negacyclic FFT64 (the reference backend's own arithmetic: complex FP64 transform of N/2 points, results rounded to the exact integers); int32 limbs in HBM",
         "data": "synthetic",
         "config": {"workload": f"Ram::read + Ram::read_prepare_write + Ram::write, MAX_ADDR=2^{log_entries}, "
                                f"WORDSIZE={ws}, N=4096, base2k=17, rank=1, "
@@ -606,98 +640,136 @@ def main():
                                 "with the hand-over inside")
 
     if not args.no_kernel_timing:
-        classes = {k: ram.profile_get(k) for k in ("keyswitch", "keyswitch_fused", "keyswitch_chain_launch", "ext_product",
-                                                   "ext_product_fused", "prepare", "elementwise", "read_chain_launch", "write_chain_launch")}
-        # the row chains as single launches (k_read_chain: coordinate 0's products + the alone packer levels; k_write_chain: the 12 trace
-        # steps of ct_lo X^-row + the elementwise step + write_last_step's products), against the same FP64 roof
+        names = ("keyswitch", "keyswitch_fused", "keyswitch_chain_launch", "keyswitch_tail_launch", "keyswitch_mid_launch", "ext_product",
+                 "ext_product_fused", "ext_product_mid_launch", "prepare", "elementwise", "read_chain_launch", "write_chain_launch")
+        classes = {k: ram.profile_get(k) for k in names}
+        forms = ram.forms() if hasattr(ram, "forms") else {}
         d0 = len(p.base2d().v[0].d)
         L0r = max(0, 12 - max(0, (-(-max_addr // N) - 1).bit_length()))
-        fused = {}
-        for name, n_ep, n_ks in (("read_chain_launch", d0, L0r), ("write_chain_launch", d0, 12)):
-            cl = classes[name]
-            if cl["launches"]:
-                per_ct = n_ep * FP64_PER_EP + n_ks * fp64_per_ks
-                t = cl["blocks"] * per_ct / (cl["ms"] * 1e-3) / 1e12
-                fused[name] = {"launches": cl["launches"], "ciphertexts_per_launch": cl["blocks"] / cl["launches"], "products": n_ep, "trace_steps": n_ks,
-                               "avg_launch_ms": cl["ms"] / cl["launches"], "achieved_T_fp64_instr_s": t, "frac": t / FP64_VALU_PEAK_TINSTR}
-        if fused:
-            out["fused_row_chains"] = dict(fused, note="HIP events around the launch, all-classes pass; read_chain = ram.rs:429-435 / 502-514, write_chain = ram.rs:612-646")
-        kf = classes["keyswitch_fused"]
-        # Dominant kernel = the fused key-switch at one workgroup per ciphertext (trace step / packer level over every
-        # row of every sub-RAM).  Dependent trace steps on the same ciphertexts run as ONE launch (k_keyswitch_chain:
-        # 6 or 12 steps at 2^18); a "launch" below is one STEP of it (the unit SURVEY.md 8(d) counts bytes for:
-        # GLWE in + GLWE out per ciphertext, the step's key once), its duration = the launch's HIP-event time / steps.
-        # `chain_launch` carries the whole-launch figures that rocprofv3 --stats reports for k_keyswitch_chain.
-        if kf["launches"]:
-            chain = classes["keyswitch_chain_launch"]
-            # the per-launch events nest (class > fused > the chain launch itself): the innermost pair brackets nothing but the
-            # kernel, the outer ones also the inner pairs' own records (a few us per launch).  When every fused step of the pass
-            # ran inside a chain launch the innermost time is the kernel time; the outer one is kept beside it.
-            inner = chain["launches"] > 0 and chain["blocks"] == kf["blocks"]
-            kf_ms = chain["ms"] if inner else kf["ms"]
-            # ... and the pass that brackets nothing but those launches is the one the roofline is priced on
-            lightly = inner and light is not None and light["chain"]["blocks"] == chain["blocks"]
-            if lightly:
-                kf_ms = light["chain"]["ms"]
-            avg_ms = kf_ms / kf["launches"]
-            blocks = kf["blocks"] / kf["launches"]
-            bytes_abi = blocks * 2 * GLWE_I64 + atk_i64              # in + out GLWE (int64 limbs) + key once
-            steps_per_launch = (chain["blocks"] / chain["launches"] / blocks) if chain["launches"] else 1.0
-            # what the device layout must move per step of a chain whose steps hand over through LDS and registers: the step's key,
-            # and its share of the launch's int32 input and output (2 x 98 304 B per ciphertext per LAUNCH)
-            bytes_dev = atk_i64 + blocks * 2 * (GLWE_I64 // 2) / max(1.0, steps_per_launch)
-            ach = kf["blocks"] * fp64_per_ks / (kf_ms * 1e-3) / 1e12            # T FP64 VALU instructions / s
-            # PRIMARY roofline = the roof that binds this kernel: the FP64 vector ALU.  Every FP64 VALU instruction
-            # (mul / add / fma / rndne: all issue at the FMA rate) is priced as one FMA slot = 2 FLOP, so that achieved
-            # and peak are in the guide's TFLOP/s; frac = instruction rate / 39.3 T instr/s.
-            form = min(int(os.environ.get("FHERAM_CHAIN_Y", "3")[:1] or 3), 3)
-            fname = {0: "ks_run<KS_TRACE,3,%d,3,NCO=2> (int32 limbs between steps)", 1: "ks_trace_y<%d> (Y form, limb-by-limb normalisation)",
-                     2: "ks_trace_z<%d> (Y form, closed-form normalisation, paired inverse transforms)",
-                     3: "ks_trace_l<%d> (closed-form normalisation, paired inverse transforms, steps handed over through LDS and registers)"}[form] % s_evk
-            out["roofline"] = {"kernel": f"fused trace step {fname} inside k_keyswitch_chain<3,{s_evk},3,{form}>, one workgroup per ciphertext",
-                               "bound": "valu_fp64", "achieved": 2 * ach, "peak": 2 * FP64_VALU_PEAK_TINSTR, "unit": "TFLOP/s",
-                               "frac": ach / FP64_VALU_PEAK_TINSTR,
-                               "achieved_T_fp64_instr_s": ach, "peak_T_fp64_instr_s": FP64_VALU_PEAK_TINSTR,
-                               "fp64_instr_per_keyswitch": fp64_per_ks,
-                               "traffic": pmc_traffic_per_launch(),
-                               "traffic_source": PMC_PROFILE + " (HBM bytes per step of this kernel: separate rocprofv3 --pmc FETCH_SIZE / "
-                                                 "WRITE_SIZE passes of this command, FETCH_SIZE scaled by the factor calibrated on a "
-                                                 "known-bytes 4-B/lane int32 stream, tools/fetch_calib.hip)",
-                               "avg_launch_ms": avg_ms, "avg_blocks_per_launch": blocks, "launches": kf["launches"],
-                               "avg_launch_ms_all_classes_pass": {"innermost_event_pair": (chain["ms"] if inner else kf["ms"]) / kf["launches"],
-                                                                  "outer_event_pair": kf["ms"] / kf["launches"]},
-                               "timing_source": ("HIP events around the chain launches only, on their launch stream, in a pass of the same K steps "
-                                                 f"that is otherwise uninstrumented ({light['elapsed'] * 1e3 / args.steps:.3f} ms per step against "
-                                                 f"{ms_per_step:.3f} in the timed region)") if lightly else "HIP events around every launch (all-classes pass)",
-                               "launch_unit": "one trace step over the batch: HIP-event time of a pure trace-chain launch / its steps (at 2^18 the write's side-stream chain, 6 steps per launch; the other 24 trace steps of a step run inside k_read_chain / k_write_chain behind / in front of the products: fused_row_chains)",
-                               "chain_launch": ({"kernel": f"k_keyswitch_chain<3,{s_evk},3,{form}>", "launches": chain["launches"],
-                                                 "avg_launch_ms": (light["chain"]["ms"] if lightly else chain["ms"]) / chain["launches"],
-                                                 "avg_steps_per_launch": chain["blocks"] / chain["launches"] / blocks}
-                                                if chain["launches"] else None),
-                               "measured_issue_peak_T_instr_s": 36.0,
-                               "measured_issue_peak_source": "profiles/r01_valu_rate.txt (tools/valu_rate.hip: mulmod chains sustain 1.8 ns per "
-                                                             "wave-instruction per SIMD at the 2.15 GHz clock of FP64 load)"}
-            ks = classes["keyswitch"]
-            if ks["launches"]:
-                cls = ks["blocks"] * fp64_per_ks / (ks["ms"] * 1e-3) / 1e12
-                out["roofline"]["whole_class"] = {"what": "every key-switch launch OUTSIDE the fused row chains: the pure trace chain, the pair levels, the trace tail and the small batches of the dependent end of an op (latency-bound)",
-                                                  "achieved_T_fp64_instr_s": cls, "frac": cls / FP64_VALU_PEAK_TINSTR,
-                                                  "avg_launch_ms": ks["ms"] / ks["launches"], "avg_blocks_per_launch": ks["blocks"] / ks["launches"]}
-            # SECONDARY: the same launches against HBM.  frac is on the bytes the DEVICE layout must move (int32 limbs, f64
-            # key); the int64-limb ABI layout of SURVEY.md 8(d) is reported beside it, labelled.
-            out["roofline_hbm"] = {"kernel": "same launches", "bound": "hbm", "achieved": bytes_dev / avg_ms / 1e6, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": bytes_dev / avg_ms / 1e6 / HBM_PEAK_GBS,
-                                   "device_layout_bytes_per_launch": bytes_dev,
-                                   "abi_layout_int64": {"algorithmic_bytes_per_launch": bytes_abi, "achieved": bytes_abi / avg_ms / 1e6,
-                                                        "frac": bytes_abi / avg_ms / 1e6 / HBM_PEAK_GBS},
-                                   "traffic": pmc_traffic_per_launch(),
-                                   "note": "not the binding roof: everything a 2^18 op touches sits in the 256 MiB Infinity Cache"}
-        # whole step (read + read_prepare_write + write) against both roofs: the op-level view of SURVEY.md 8(d)
+        # Every launch class that a step's GPU time splits into (disjoint: the nested event pairs are subtracted), with the FP64
+        # work its launches carry (per ciphertext: products x FP64_PER_EP + key-switches x fp64_per_ks) and the kernel it is.
+        def entry(kernel, what, ms, launches, fp64, pmc=None, steps_per_launch=None):
+            if not launches or ms <= 0:
+                return None
+            t = fp64 / (ms * 1e-3) / 1e12
+            e = {"kernel": kernel, "what": what, "launches": launches, "avg_launch_ms": ms / launches, "gpu_ms": ms,
+                 "achieved_T_fp64_instr_s": t, "achieved": 2 * t, "peak": 2 * FP64_VALU_PEAK_TINSTR, "unit": "TFLOP/s", "bound": "valu_fp64",
+                 "frac": t / FP64_VALU_PEAK_TINSTR, "traffic": pmc_traffic(pmc) if pmc else None}
+            if steps_per_launch:
+                e["steps_per_launch"] = steps_per_launch
+            return e
+        rc, wc, pc = classes["read_chain_launch"], classes["write_chain_launch"], classes["keyswitch_chain_launch"]
+        tl, md, mde = classes["keyswitch_tail_launch"], classes["keyswitch_mid_launch"], classes["ext_product_mid_launch"]
+        ksc, epc = classes["keyswitch"], classes["ext_product"]
+        pure_ms = light["chain"]["ms"] if (light is not None and light["chain"]["blocks"] == pc["blocks"] and pc["launches"]) else pc["ms"]
+        rest_ks_ms = ksc["ms"] - pc["ms"] - tl["ms"] - md["ms"]
+        rest_ks_blocks = ksc["blocks"] - pc["blocks"] - tl["blocks"] - md["blocks"]
+        rest_ep_ms = epc["ms"] - mde["ms"]
+        rest_ep_blocks = epc["blocks"] - mde["blocks"]
+        sk = s_evk
+        table = [
+            entry(f"k_read_chain<{sk},4>", f"a row's {d0} products of coordinate 0 + its {L0r} alone packer levels as ONE launch, one workgroup per row (ram.rs:429-435,502-514)",
+                  rc["ms"], rc["launches"], rc["blocks"] * (d0 * FP64_PER_EP + L0r * fp64_per_ks), f"fk::k_read_chain<{sk}, 4>", d0 + L0r),
+            entry(f"k_write_chain<{sk},4>", f"write_mid_step's 12 trace steps of ct_lo X^-row + normalize(ct_hi - trace(ct_hi) + .) + write_last_step's {d0} products as ONE launch (ram.rs:612-646)",
+                  wc["ms"], wc["launches"], wc["blocks"] * (d0 * FP64_PER_EP + 12 * fp64_per_ks), f"fk::k_write_chain<{sk}, 4>", d0 + 12),
+            entry(f"k_keyswitch_chain<3,{sk},3,{forms.get('chain_y', 3)}>", "pure trace chains, one workgroup per ciphertext (at 2^18: trace(ct_hi) steps 6..11 on the write's side stream, ram.rs:616)",
+                  pure_ms, pc["launches"], pc["blocks"] * fp64_per_ks, f"fk::k_keyswitch_chain<3, {sk}, 3, {forms.get('chain_y', 3)}>",
+                  (pc["blocks"] / pc["launches"] / max(1.0, classes["keyswitch_fused"]["blocks"] / max(1, classes["keyswitch_fused"]["launches"]))) if pc["launches"] else None),
+            entry(f"k_trace_tail<3,{sk},3>", "GLWE::trace on the word_size results at the end of a read: 12 dependent steps as one launch with in-kernel hand-offs (ram.rs:457,540)",
+                  tl["ms"], tl["launches"], tl["blocks"] * fp64_per_ks, f"fk::k_trace_tail<3, {sk}, 3>"),
+            entry("k_chain_mid<...>", "dependent chains on 9..64 ciphertexts as one launch with in-kernel hand-offs (MAX_ADDR 2^13..2^16)",
+                  md["ms"] + mde["ms"], md["launches"] + mde["launches"], md["blocks"] * fp64_per_ks + mde["blocks"] * FP64_PER_EP),
+            entry("k_pair_z / k_keyswitch / k_keyswitch_fine + _norm", "the pair levels of the packing tree and the other key-switch launches of the dependent end of an op (4..128 ciphertexts per launch)",
+                  rest_ks_ms, ksc["launches"] - pc["launches"] - tl["launches"] - md["launches"], rest_ks_blocks * fp64_per_ks),
+            entry("k_ext_product_fine + _norm / k_ext_product", "coordinate 1's products on word_size ciphertexts",
+                  rest_ep_ms, epc["launches"] - mde["launches"], rest_ep_blocks * FP64_PER_EP),
+            entry("k_prepare", "CoordinatePrepared::prepare: forward transforms of the address digits", classes["prepare"]["ms"], classes["prepare"]["launches"],
+                  classes["prepare"]["blocks"] * FP64_FWD),
+            entry("elementwise (k_sub_add_norm, k_rotate, k_copy)", "write_first_step, rotations, copies", classes["elementwise"]["ms"], classes["elementwise"]["launches"], 0),
+        ]
+        table = [e for e in table if e]
+        gpu_ms = sum(e["gpu_ms"] for e in table)
+        for e in table:
+            e["share_of_gpu_time"] = e["gpu_ms"] / gpu_ms
+        table.sort(key=lambda e: -e["gpu_ms"])
+        note = ("frac prices the implementation's OWN FP64 instruction stream (6 / 8 instructions per complex butterfly of the FFT64 transforms, 4 per "
+                "complex MAC, 1 per rounding) against the 39.3 T instr/s issue peak: utilisation of the FP64 pipe, not a bound on the "
+                "algorithm.  Round 5 replaced round 4's modular transforms (8 instructions per butterfly on twice as many points, 7 per "
+                "MAC: 2.47x the FP64 instructions per key-switch, 2.66x per product) — the same launch at round 4's count is "
+                "frac_at_round4_instruction_count, for comparison with the r04 profiles only.  What now shares the step with the FP64 "
+                "pipe: the swap rounds and address arithmetic of the transforms (VALU, not FP64), two 32 KB LDS exchanges per transform, and "
+                "the prepared operands streamed from L2 (32 KB per polynomial MAC at the CU's 64 B/clk): see `pipes`.")
+        if table:
+            dom = dict(table[0])
+            ratio = None
+            if dom["kernel"].startswith("k_read_chain"):
+                ratio = (d0 * R04_FP64_PER_EP + L0r * R04_FP64_PER_KS) / (d0 * FP64_PER_EP + L0r * FP64_PER_KS) if s_evk == 4 else None
+                n_ep, n_ks = d0, L0r
+            elif dom["kernel"].startswith("k_write_chain"):
+                ratio = (d0 * R04_FP64_PER_EP + 12 * R04_FP64_PER_KS) / (d0 * FP64_PER_EP + 12 * FP64_PER_KS) if s_evk == 4 else None
+                n_ep, n_ks = d0, 12
+            else:
+                ratio = R04_FP64_PER_KS / FP64_PER_KS if s_evk == 4 else None
+                n_ep, n_ks = 0, 1
+            dom["note"] = note
+            dom["frac_at_round4_instruction_count"] = None if ratio is None else dom["frac"] * ratio
+            dom["fp64_instr_per_keyswitch"] = fp64_per_ks
+            dom["fp64_instr_per_product"] = FP64_PER_EP
+            dom["traffic_source"] = PMC_PROFILE + " (HBM-side bytes per launch of this kernel: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE scaled by the factor calibrated on a known-bytes stream, tools/fetch_calib.hip; FETCH_SIZE counts Infinity-Cache hits)"
+            dom["timing_source"] = "HIP events around each launch of the class on its launch stream, in a pass of the same K steps (not the timed region)"
+            # the other pipes a chain step keeps busy, per ciphertext, from the kernel's structure (csrc/fft_dev.hpp, kernels.hpp)
+            n_tr = n_ep * 14 + n_ks * (3 + 2 * s_evk)
+            n_mac = n_ep * 48 + n_ks * 6 * s_evk
+            t_launch = dom["avg_launch_ms"] * 1e-3
+            lds_bytes = n_tr * 2 * 2 * 32768 + n_tr * 13 * 16 * 512        # two exchanges (write + read) + 13 twiddle reads of 16 B per thread
+            opnd_bytes = n_mac * 32768
+            dom["pipes"] = {"what": "per workgroup (= per CU: one ciphertext each) and launch, from the kernel's structure; rates against the CU's own peaks at the clock the stamps show (2.19 GHz)",
+                            "transforms": n_tr, "polynomial_macs": n_mac,
+                            "fp64_busy_frac": dom["frac"],
+                            "lds_bytes": lds_bytes, "lds_GBs_per_cu": lds_bytes / t_launch / 1e9, "lds_peak_GBs_per_cu": "~85 B/clk stores, 256 B/clk loads (MI355X_MICROARCH.md LDS table): 186 / 560",
+                            "operand_bytes_from_l2": opnd_bytes, "operand_GBs_per_cu": opnd_bytes / t_launch / 1e9, "operand_peak_GBs_per_cu": 64 * 2.19,
+                            "operand_frac": opnd_bytes / t_launch / 1e9 / (64 * 2.19)}
+            out["roofline"] = dom
+            out["roofline_by_kernel"] = {"what": "every launch class of the step (disjoint), largest GPU time first; share_of_gpu_time is of the summed kernel time of the instrumented pass",
+                                         "kernels": [{k: v for k, v in e.items()} for e in table if e["share_of_gpu_time"] >= 0.05],
+                                         "below_5_percent": [{"kernel": e["kernel"], "share_of_gpu_time": e["share_of_gpu_time"], "avg_launch_ms": e["avg_launch_ms"], "frac": e["frac"]} for e in table if e["share_of_gpu_time"] < 0.05]}
+            # the pure trace step (what rounds 2-4 priced): one step of a pure trace chain over the batch
+            if pc["launches"]:
+                kf = classes["keyswitch_fused"]
+                blocks = kf["blocks"] / kf["launches"] if kf["launches"] else 0
+                spl = pc["blocks"] / pc["launches"] / blocks if blocks else 1.0
+                step_ms = pure_ms / pc["launches"] / spl
+                bytes_abi = blocks * 2 * GLWE_I64 + atk_i64              # in + out GLWE (int64 limbs) + key once
+                bytes_dev = atk_i64 + blocks * 2 * (GLWE_I64 // 2) / max(1.0, spl)
+                out["trace_step"] = {"what": "one fused trace step (ks_trace_l) over the batch: HIP-event time of a pure trace-chain launch / its steps",
+                                     "us": step_ms * 1e3, "ciphertexts": blocks, "steps_per_launch": spl,
+                                     "frac": blocks * fp64_per_ks / (step_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR,
+                                     "round4_us": 33.3}
+                out["roofline_hbm"] = {"kernel": "the same trace step", "bound": "hbm", "achieved": bytes_dev / step_ms / 1e6, "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": bytes_dev / step_ms / 1e6 / HBM_PEAK_GBS,
+                                       "device_layout_bytes_per_launch": bytes_dev,
+                                       "abi_layout_int64": {"algorithmic_bytes_per_launch": bytes_abi, "achieved": bytes_abi / step_ms / 1e6,
+                                                            "frac": bytes_abi / step_ms / 1e6 / HBM_PEAK_GBS},
+                                       "note": "not the binding roof: everything a 2^18 op touches sits in the 256 MiB Infinity Cache"}
+        if rc["launches"] or wc["launches"]:
+            out["fused_row_chains"] = {e["kernel"].split("<")[0]: {k: e[k] for k in ("launches", "avg_launch_ms", "frac", "steps_per_launch") if k in e}
+                                       for e in table if e["kernel"].startswith(("k_read_chain", "k_write_chain"))}
+        # whole step (read + read_prepare_write + write) against both roofs, and in SURVEY.md 8(d)'s own unit
         ep_ref = 2 * cnt["ep_read"] + cnt["ep_write"]
         ks_ref = 2 * cnt["ks_read"] + cnt["ks_write"]
         L0 = max(0, 12 - max(0, (cnt["rows"] - 1).bit_length())) if cnt["rows"] > 1 else 0
         ks_exec = ks_ref - (ws * 12 + ws * cnt["rows"] * L0)     # the write resumes from what read_prepare_write kept (csrc/path.hpp)
         fp_step = ep_ref * FP64_PER_EP + ks_exec * fp64_per_ks
+        mm_ks = modmul_per_keyswitch(s_evk)
+        mm = {"read": cnt["ep_read"] * MODMUL_PER_EP + cnt["ks_read"] * mm_ks,
+              "read_prepare_write": cnt["ep_read"] * MODMUL_PER_EP + cnt["ks_read"] * mm_ks,
+              "write": cnt["ep_write"] * MODMUL_PER_EP + cnt["ks_write"] * mm_ks}
+        out["modmul_per_s"] = {"what": "SURVEY.md 8(d)'s unit: the reference's operation count per op (a butterfly of an N-point transform = 1 modmul, 24 576 per transform; a pointwise MAC = 4096 per polynomial pair; EP = 540 672, trace / pack key-switch = 368 640 with 4-limb keys) / the op's time.  Counts follow the REFERENCE's control flow (a write counts all 24 traces per row although this path resumes from what read_prepare_write kept); GGSW prepares and inversions (< 2 %) not counted.  The >= 100x target needed 0.28 T/s",
+                               "unit": "T modmul/s",
+                               "read": mm["read"] / (read_ms * 1e-3) / 1e12, "read_prepare_write": mm["read_prepare_write"] / (rpw_ms * 1e-3) / 1e12,
+                               "write": mm["write"] / (write_ms * 1e-3) / 1e12,
+                               "step": (mm["read"] + mm["read_prepare_write"] + mm["write"]) / (ms_per_step * 1e-3) / 1e12,
+                               "modmuls_per_op": mm}
         out["roofline_whole_op"] = {"what": "one step = read + read_prepare_write + write, device-resident, against the same two roofs",
                                     "hbm": {"algorithmic_bytes_per_step": a_read + a_rpw + a_write,
                                             "achieved_GBs": (a_read + a_rpw + a_write) / ms_per_step / 1e6,
@@ -711,6 +783,7 @@ def main():
         out["kernel_timing_pass"] = {"what": "separate pass of the same K steps with per-launch HIP events on the launch stream "
                                              "(not part of the timed region: the events add this much to a step)",
                                      "ms_per_step_instrumented": instr_elapsed * 1e3 / args.steps}
+        out["forms"] = forms
 
     parity_failed = False
     if not args.no_cpu_baseline and world == 1 and mode == "single":   # reported baseline: rank 0 at N = 1 only

@@ -42,6 +42,15 @@ class _CParams(C.Structure):
                 ("decomp_n", C.c_uint8 * 16), ("max_addr", C.c_uint64)]
 
 
+_CONFIG_FIELDS = ("limb_split", "fine_split", "memo", "pre_inv", "tail", "tail_test", "mid", "mid_test", "chain", "chain_y", "pair_z",
+                  "fuse", "graph", "safe", "nco", "reserved")
+
+
+class _CConfig(C.Structure):
+    """fheram_config (include/fheram.h): the execution switches of a context"""
+    _fields_ = [(f, C.c_int32) for f in _CONFIG_FIELDS]
+
+
 def library_path() -> str:
     # FHERAM_LIB selects an alternative build of the same HIP library (kernel-tuning experiments)
     return os.environ.get("FHERAM_LIB") or os.path.join(_HERE, "libfheram.so")
@@ -75,6 +84,9 @@ _SYMBOLS = [
     ("fheram_result_map", C.c_int, [C.c_void_p, C.POINTER(I64P)]),
     ("fheram_sync", C.c_int, [C.c_void_p]),
     ("fheram_ctx_create_sharded", C.c_int, [C.POINTER(_CParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("fheram_config_default", None, [C.POINTER(_CConfig)]),
+    ("fheram_ctx_create_cfg", C.c_int, [C.POINTER(_CParams), C.c_int, C.c_int, C.c_int, C.POINTER(_CConfig), C.POINTER(C.c_void_p)]),
+    ("fheram_ctx_config", C.c_int, [C.c_void_p, C.POINTER(_CConfig)]),
     ("fheram_shard_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     ("fheram_stream_signal", C.c_int, [C.c_void_p, C.c_void_p]),
     ("fheram_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -511,20 +523,36 @@ class GLWESecret:
 class Ram:
     """ram.rs:25-29.  Owns the device-resident sub-RAMs, tree, packer scratch and prepared keys."""
 
-    def __init__(self, params: Optional[Parameters] = None, device: int = 0, shard: int = 0, n_shards: int = 1):
+    def __init__(self, params: Optional[Parameters] = None, device: int = 0, shard: int = 0, n_shards: int = 1, config: Optional[dict] = None):
         """shard / n_shards: row sharding across GPUs; this context then owns rows
-        r = shard (mod n_shards) of every sub-RAM and only the *_partial / *_root / *_shard ops apply."""
+        r = shard (mod n_shards) of every sub-RAM and only the *_partial / *_root / *_shard ops apply.
+        config: execution switches that differ from fheram_config_default() (fheram_config's field names)."""
         self.params = params or Parameters.new()
         self.shard, self.n_shards = int(shard), int(n_shards)
         self._h = None
         L = library()
         out = C.c_void_p()
         cp = self.params._c()
-        rc = L.fheram_ctx_create_sharded(C.byref(cp), device, self.shard, self.n_shards, C.byref(out))
+        if config:
+            cfg = _CConfig()
+            L.fheram_config_default(C.byref(cfg))
+            for k, v in config.items():
+                if k not in _CONFIG_FIELDS:
+                    raise FheRamError(1, f"unknown execution switch {k!r}")
+                setattr(cfg, k, int(v))
+            rc = L.fheram_ctx_create_cfg(C.byref(cp), device, self.shard, self.n_shards, C.byref(cfg), C.byref(out))
+        else:
+            rc = L.fheram_ctx_create_sharded(C.byref(cp), device, self.shard, self.n_shards, C.byref(out))
         if rc != 0:
             raise FheRamError(rc, L.fheram_last_error(None).decode())
         self._h = out.value
         self._keys = None
+
+    def forms(self) -> dict:
+        """the execution switches in effect on this context (fheram_ctx_config)"""
+        cfg = _CConfig()
+        self._chk(library().fheram_ctx_config(self._h, C.byref(cfg)))
+        return {f: int(getattr(cfg, f)) for f in _CONFIG_FIELDS if f != "reserved"}
 
     @classmethod
     def new(cls, device: int = 0):  # ram.rs:59

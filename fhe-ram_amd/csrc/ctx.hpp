@@ -76,7 +76,7 @@ struct fheram_ctx {
     double* d_big2 = nullptr;      // same, for launches on the side stream
     int limb_split = 1;            // FHERAM_LIMB_SPLIT=0 disables the limb-parallel paths
     int chain = 1;                 // FHERAM_CHAIN=0: one launch per step instead of one launch per dependent chain of fused steps
-    int chain_y = 3;               // FHERAM_CHAIN_Y=0: the intermediates of a trace chain as int32 limbs; 1: as Y = ceil(A/2) with the limb-by-limb normalisation (ks_trace_y, round 3); 2: Y with the closed-form normalisation (ks_trace_z); 3: the same, handed over through LDS and registers (ks_trace_l)
+    int chain_y = 3;               // 3: the intermediates of a trace chain as Y = ceil(A/2) with the closed-form normalisation, handed over through LDS and registers (ks_trace_l); 0 (FHERAM_CHAIN_Y=0): as int32 limbs through global memory (ks_run)
     int fine_split = 1;            // FHERAM_FINE_SPLIT=0 disables the fine limb split (one workgroup per input and output limb)
     int use_graph = 0;             // FHERAM_GRAPH=1: replay each op's launch sequence from a hipGraph (per address)
     int32_t* d_part = nullptr;     // [ws]            this shard's partial pack / the un-rotated ct_lo
@@ -132,7 +132,6 @@ struct fheram_ctx {
     //              with another address, or after new keys, computes them itself.  FHERAM_PRE_INV=0: always.
     int pair_z = 1;                // FHERAM_PAIR_Z=0: the column-split packer combine with the limb-by-limb normalisation (k_keyswitch<KS_PAIR,...,1>) instead of k_pair_z
     int fuse = 1;                  // FHERAM_FUSE=0: a row's product chain and trace chain as two launches (and the write's elementwise step as a third) instead of k_read_chain / k_write_chain
-    int ep_r = 1;                  // FHERAM_EP_R=0: the products of a fused product chain hand over through global memory as int32 limbs (k_ext_product_chain, round 3) instead of in registers / LDS (k_ext_product_chain_r)
     int safe = 0;                  // FHERAM_SAFE=1: no in-kernel hand-offs between workgroups, no gate wave (fheram.hip)
     int pre_inv = 1;
     uint64_t inv_id[2] = {0, 0};

@@ -21,11 +21,43 @@ int fheram_params_default(fheram_params* p) {
 
 const char* fheram_last_error(const fheram_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+// Library defaults, then FHERAM_* environment overrides (how the tests force every decomposition and hand-over form).
+void fheram_config_default(fheram_config* cfg) {
+    if (!cfg) return;
+    fheram_config d{};
+    d.limb_split = 1; d.fine_split = 1; d.memo = 1; d.pre_inv = 1; d.tail = 1; d.tail_test = 0; d.mid = 2; d.mid_test = 0;
+    d.chain = 1; d.chain_y = 3; d.pair_z = 1; d.fuse = 1; d.graph = 0; d.safe = 0; d.nco = 0;
+    auto env = [](const char* n) { const char* v = getenv(n); return (v && v[0]) ? v[0] : '\0'; };
+    if (env("FHERAM_LIMB_SPLIT") == '0') d.limb_split = 0;
+    if (env("FHERAM_FINE_SPLIT") == '0') d.fine_split = 0;
+    if (env("FHERAM_MEMO") == '0') d.memo = 0;
+    if (env("FHERAM_PRE_INV") == '0') d.pre_inv = 0; else if (env("FHERAM_PRE_INV") == '2') d.pre_inv = 2;
+    const char tl = env("FHERAM_TAIL");
+    if (tl == '0') d.tail = 0;
+    d.tail_test = tl == '2' ? 1 : (tl == '3' ? 2 : 0);
+    const char md = env("FHERAM_MID");
+    d.mid = md == '0' ? 0 : (md == '1' ? 1 : 2);
+    d.mid_test = md == '2' ? 1 : 0;
+    if (env("FHERAM_CHAIN") == '0') d.chain = 0;
+    if (env("FHERAM_CHAIN_Y") == '0') d.chain_y = 0;
+    if (env("FHERAM_PAIR_Z") == '0') d.pair_z = 0;
+    if (env("FHERAM_FUSE") == '0') d.fuse = 0;
+    if (env("FHERAM_GRAPH") == '1') d.graph = 1;
+    if (env("FHERAM_SAFE") == '1') d.safe = 1;
+    const char nc = env("FHERAM_NCO");
+    d.nco = nc == '2' ? 2 : (nc == '1' ? 1 : 0);
+    *cfg = d;
+}
+
 int fheram_ctx_create(const fheram_params* p, int device, fheram_ctx** out) {
-    return fheram_ctx_create_sharded(p, device, 0, 1, out);
+    return fheram_ctx_create_cfg(p, device, 0, 1, nullptr, out);
 }
 
 int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int n_shards, fheram_ctx** out) {
+    return fheram_ctx_create_cfg(p, device, shard, n_shards, nullptr, out);
+}
+
+int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_shards, const fheram_config* user_cfg, fheram_ctx** out) {
     if (!p || !out) return fail(nullptr, FHERAM_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
     if (n_shards < 1 || shard < 0 || shard >= n_shards || (n_shards & (n_shards - 1)) != 0)
@@ -103,46 +135,33 @@ int fheram_ctx_create_sharded(const fheram_params* p, int device, int shard, int
     CCHK(hipEventCreate(&c->t0));
     CCHK(hipEventCreate(&c->t1));
     {
-        const char* ls = getenv("FHERAM_LIMB_SPLIT");
-        c->limb_split = (ls && ls[0] == '0') ? 0 : 1;
-        const char* fs = getenv("FHERAM_FINE_SPLIT");
-        c->fine_split = (fs && fs[0] == '0') ? 0 : 1;
-        const char* mm = getenv("FHERAM_MEMO");
-        c->memo = (mm && mm[0] == '0') ? 0 : 1;
-        const char* pi = getenv("FHERAM_PRE_INV");
-        c->pre_inv = (c->memo && !(pi && pi[0] == '0')) ? ((pi && pi[0] == '2') ? 2 : 1) : 0;
-        const char* tl = getenv("FHERAM_TAIL");
-        c->tail = (tl && tl[0] == '0') ? 0 : 1;
+        fheram_config cfg;
+        if (user_cfg) cfg = *user_cfg; else fheram_config_default(&cfg);
+        c->limb_split = cfg.limb_split ? 1 : 0;
+        c->fine_split = cfg.fine_split ? 1 : 0;
+        c->memo = cfg.memo ? 1 : 0;
+        c->pre_inv = c->memo ? (cfg.pre_inv == 2 ? 2 : (cfg.pre_inv ? 1 : 0)) : 0;
+        c->tail = cfg.tail ? 1 : 0;
         static std::atomic<int> serial{0};
         c->tail_xoff = ((serial++ + (int)getpid()) & 1) * (TAIL_GROUPS / 2);
-        c->tail_test = (tl && tl[0] == '2') ? 1 : ((tl && tl[0] == '3') ? 2 : 0);
-        const char* md = getenv("FHERAM_MID");
-        c->mid = (md && md[0] == '0') ? 0 : ((md && md[0] == '1') ? 1 : 2);   // 1: the <= 16 ciphertext split only
-        c->mid_test = (md && md[0] == '2') ? 1 : 0;
-        const char* ch = getenv("FHERAM_CHAIN");
-        c->chain = (ch && ch[0] == '0') ? 0 : 1;
-        const char* cy = getenv("FHERAM_CHAIN_Y");
-        c->chain_y = (cy && cy[0] == '0') ? 0 : 3;
-        const char* pz = getenv("FHERAM_PAIR_Z");
-        c->pair_z = (pz && pz[0] == '0') ? 0 : 1;
-        const char* fu = getenv("FHERAM_FUSE");
-        c->fuse = (fu && fu[0] == '0') ? 0 : 1;
-        const char* er = getenv("FHERAM_EP_R");
-        c->ep_r = (er && er[0] == '0') ? 0 : 1;
-        const char* gr = getenv("FHERAM_GRAPH");
-        c->use_graph = (gr && gr[0] == '1') ? 1 : 0;
+        c->tail_test = cfg.tail_test;
+        c->mid = cfg.mid < 0 ? 0 : (cfg.mid > 2 ? 2 : cfg.mid);   // 1: the <= 16 ciphertext split only
+        c->mid_test = cfg.mid_test ? 1 : 0;
+        c->chain = cfg.chain ? 1 : 0;
+        c->chain_y = cfg.chain_y ? 3 : 0;
+        c->pair_z = cfg.pair_z ? 1 : 0;
+        c->fuse = cfg.fuse ? 1 : 0;
+        c->use_graph = cfg.graph ? 1 : 0;
         // a captured launch sequence must be a pure function of (context, address, op): under replay the write always
         // computes its own inverse digits (whether a precompute matched is state the capture would freeze)
         if (c->use_graph) c->pre_inv = 0;
-        // FHERAM_SAFE=1: ONE switch for a configuration that stays inside the HIP memory model — no launch with in-kernel hand-offs
+        // safe: ONE switch for a configuration that stays inside the HIP memory model — no launch with in-kernel hand-offs
         // between workgroups (k_trace_tail, k_chain_mid: relaxed agent-scope atomics + drained stores + L1-bypassing loads on one
         // XCD's L2) and no gate wave (k_tail_gate): dependent steps are kernel boundaries, the side work forks from an event.
-        // Same results (tests/test_gpu_golden.py); priced in profiles/r04_bench_safe.json.
-        const char* sf = getenv("FHERAM_SAFE");
-        c->safe = (sf && sf[0] == '1') ? 1 : 0;
+        // Same results (tests/test_gpu_golden.py); priced in profiles/r05_bench_safe.json.
+        c->safe = cfg.safe ? 1 : 0;
         if (c->safe) { c->tail = 0; c->tail_test = 0; c->mid = 0; c->mid_test = 0; if (c->pre_inv == 1) c->pre_inv = 2; }
-        const char* e = getenv("FHERAM_NCO");
-        c->nco = (e && e[0] == '2') ? 2 : ((e && e[0] == '1') ? 1 : 0);
+        c->nco = cfg.nco == 2 ? 2 : (cfg.nco == 1 ? 1 : 0);
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
     }
@@ -266,6 +285,16 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->ev_w) hipEventDestroy(c->ev_w);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
+}
+
+int fheram_ctx_config(const fheram_ctx* c, fheram_config* out) {
+    if (!c || !out) return FHERAM_ERR_INVALID_ARG;
+    fheram_config d{};
+    d.limb_split = c->limb_split; d.fine_split = c->fine_split; d.memo = c->memo; d.pre_inv = c->pre_inv; d.tail = c->tail; d.tail_test = c->tail_test;
+    d.mid = c->mid; d.mid_test = c->mid_test; d.chain = c->chain; d.chain_y = c->chain_y; d.pair_z = c->pair_z; d.fuse = c->fuse;
+    d.graph = c->use_graph; d.safe = c->safe; d.nco = c->nco;
+    *out = d;
+    return FHERAM_OK;
 }
 
 size_t fheram_glwe_len(const fheram_ctx*) { return fheram_ctx::GLWE; }

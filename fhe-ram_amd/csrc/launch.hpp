@@ -219,7 +219,7 @@ void launch_ep_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], const do
     EpChainArgs ca;
     ca.src = src; ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.tw = c->d_tw; ca.n = d;
     for (int i = 0; i < d; i++) ca.ggsw[i] = prep + (size_t)i * fheram_ctx::GGSW;
-    if (c->ep_r && d >= 2) hipLaunchKernelGGL((k_ext_product_chain_r<4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);   // closed-form normalisation, products handed over in registers / LDS
+    if (d >= 2) hipLaunchKernelGGL((k_ext_product_chain_r<4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);   // closed-form normalisation, products handed over in registers / LDS
     else hipLaunchKernelGGL((k_ext_product_chain<3, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
 }
 // CoordinatePrepared::product / product_inplace (coordinate_prepared.rs:147-177): d external products.
@@ -260,7 +260,7 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
 // The two chains a row goes through back to back as ONE launch (k_read_chain / k_write_chain): both must be in the fused,
 // one-workgroup-per-ciphertext regime, in the forms that hand over through LDS and registers.
 bool use_row_fuse(const fheram_ctx* c, int d, int n_tr, int gx, int gy) {
-    return c->fuse && c->chain_y == 3 && c->ep_r && d >= 2 && d <= CHAIN_MAX && n_tr >= 2 && n_tr <= CHAIN_MAX &&
+    return c->fuse && c->chain_y == 3 && d >= 2 && d <= CHAIN_MAX && n_tr >= 2 && n_tr <= CHAIN_MAX &&
            use_chain(c, d, gx, gy, 4) && !use_mid(c, d, gx, gy, 4, true) && !use_fine_split(c, gx, gy, 2 * 4 * 2 * 3) &&
            use_chain(c, n_tr, gx, gy, c->s_evk) && !use_mid(c, n_tr, gx, gy, c->s_evk) && !use_fine_split(c, gx, gy, 2 * c->s_evk * 3) &&
            !(c->use_graph && !c->profile);

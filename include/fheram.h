@@ -125,6 +125,36 @@ int fheram_sync(fheram_ctx* ctx);
  * [limb][col][N] order (*_on_device = 1; the pointer must be valid on the context's device —
  * this is what an RCCL collective moves). */
 int fheram_ctx_create_sharded(const fheram_params* params, int device, int shard, int n_shards, fheram_ctx** out);
+
+/* Execution switches of a context: which decomposition / hand-over form the launchers of csrc/launch.hpp choose.  Every setting
+ * computes the same results (tests/test_gpu_parity.py and test_gpu_golden.py force each one); the defaults are the fastest
+ * measured forms.  fheram_config_default() fills the library defaults and then applies the FHERAM_* environment overrides of
+ * the same names (FHERAM_LIMB_SPLIT, _FINE_SPLIT, _MEMO, _PRE_INV, _TAIL, _MID, _CHAIN, _CHAIN_Y, _PAIR_Z, _FUSE, _GRAPH,
+ * _SAFE, _NCO); fheram_ctx_create / _sharded use exactly that.  No reference counterpart (the reference has one code path). */
+typedef struct fheram_config {
+    int32_t limb_split;   /* 1: limb-parallel launches for batches far smaller than the chip */
+    int32_t fine_split;   /* 1: one forward + one inverse transform per workgroup for <= 10 key-switches / <= 5 products */
+    int32_t memo;         /* 1: Ram::write resumes from what read_prepare_write computed on the unchanged state */
+    int32_t pre_inv;      /* 1: read_prepare_write starts the write's inverse digits behind a gate wave; 2: behind an event; 0: never */
+    int32_t tail;         /* 1: the trace chain at the end of a read as one launch with in-kernel hand-offs (k_trace_tail) */
+    int32_t tail_test;    /* test hook: 1 / 2 = every such launch gives up late (2 keeps the watch active) */
+    int32_t mid;          /* 2: dependent chains on 9..64 ciphertexts as one launch (k_chain_mid); 1: the <= 16 split only; 0: off */
+    int32_t mid_test;     /* test hook: one member of every such launch gives up */
+    int32_t chain;        /* 1: a dependent chain of fused steps as one launch */
+    int32_t chain_y;      /* 3: trace chains hand over through LDS and registers (ks_trace_l); 0: int32 limbs through global memory */
+    int32_t pair_z;       /* 1: the column-split packer combine in closed form (k_pair_z) */
+    int32_t fuse;         /* 1: a row's product chain and trace chain as one launch (k_read_chain / k_write_chain) */
+    int32_t graph;        /* 1: replay each op's launch sequence from a hipGraph */
+    int32_t safe;         /* 1: no in-kernel hand-offs between workgroups, no gate wave: stays inside the HIP memory model */
+    int32_t nco;          /* output columns per workgroup: 1, 2, or 0 = chosen per launch */
+    int32_t reserved;
+} fheram_config;
+void fheram_config_default(fheram_config* cfg);
+/* fheram_ctx_create_sharded with explicit switches (cfg == NULL: fheram_config_default) */
+int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_shards, const fheram_config* cfg, fheram_ctx** out);
+/* the switches IN EFFECT on this context (after `safe`, `graph` and `memo` have been applied to the others) */
+int fheram_ctx_config(const fheram_ctx* ctx, fheram_config* out);
+
 /* Stream ordering for DEVICE buffers (*_on_device = 1).  The evaluator enqueues on its own HIP stream;
  * a collective (RCCL) runs on the caller's.  Hand-overs of device buffers are asynchronous: no call
  * below blocks the host for them.  The caller orders the two streams with events instead:

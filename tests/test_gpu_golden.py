@@ -68,12 +68,11 @@ def test_hip_flow_matches_committed_digests(po, key):
 
 @pytest.mark.parametrize("env", [{"FHERAM_LIMB_SPLIT": "0", "FHERAM_NCO": "1"}, {"FHERAM_LIMB_SPLIT": "0", "FHERAM_NCO": "2", "FHERAM_CHAIN": "0"},
                                  {"FHERAM_FINE_SPLIT": "0"}, {"FHERAM_MEMO": "0"}, {"FHERAM_GRAPH": "1"}, {"FHERAM_TAIL": "2"},
-                                 {"FHERAM_CHAIN_Y": "0"}, {"FHERAM_PRE_INV": "0"}, {"FHERAM_CHAIN_Y": "1"}, {"FHERAM_SAFE": "1"},
-                                 {"FHERAM_CHAIN_Y": "2", "FHERAM_EP_R": "0"},
+                                 {"FHERAM_CHAIN_Y": "0"}, {"FHERAM_PRE_INV": "0"}, {"FHERAM_SAFE": "1"},
                                  {"FHERAM_FUSE": "0", "FHERAM_PAIR_Z": "0"}],
                          ids=["column-split", "fused-unchained", "limb-parallel", "write-recomputes", "hipgraph-replay", "tail-gives-up",
-                              "limb-handover", "write-inverts", "limb-by-limb-normalisation", "safe-no-inkernel-handoffs",
-                              "chains-hand-over-through-global-memory", "row-chains-as-separate-launches-old-combine"])
+                              "limb-handover", "write-inverts", "safe-no-inkernel-handoffs",
+                              "row-chains-as-separate-launches-old-combine"])
 def test_forced_decompositions_reproduce_the_2_18_digests(env):
     """The launch heuristics are tuned on one chip shape and one RAM size; every alternative decomposition is forced at 2^14
     in test_gpu_parity.py — and here at the FULL size of BASELINE.json configs[2..3] (256 ciphertexts per round: the fused chain
