@@ -1,10 +1,9 @@
 set -x
-# Collects the round's profile set on an MI355X box (run through gpurun); summaries land in gpurun_out/r4q, from where
+# Collects the round's profile set on an MI355X box (run through gpurun); summaries land in gpurun_out/r5q, from where
 # the ones to be judged are copied into profiles/.  Counters are collected in separate passes (FETCH_SIZE, WRITE_SIZE, SQ).
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r4q; mkdir -p $O
-for t in fetch_calib xcd_handoff xcd_barrier; do [ -x $R/tools/$t ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/$t $R/tools/$t.hip; done
-[ -x $R/tools/lds_valu_overlap ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -I$R/fhe-ram_amd/csrc -o $R/tools/lds_valu_overlap $R/tools/lds_valu_overlap.hip
-[ -x $R/tools/ntt_bench ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I$R/fhe-ram_amd/csrc -o $R/tools/ntt_bench $R/tools/ntt_bench.hip
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r5q; mkdir -p $O
+for t in fetch_calib; do [ -x $R/tools/$t ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/$t $R/tools/$t.hip; done
+[ -x $R/tools/fft_bench ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -Wno-unused-result -I$R/fhe-ram_amd/csrc -o $R/tools/fft_bench $R/tools/fft_bench.hip
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-boundary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-boundary > $O/stats.json 2> $O/stats.err
@@ -35,10 +34,7 @@ python bench.py --params readme > $O/bench_readme.json 2> $O/bench_readme.err
 python tools/chain_bench.py 256 600 > $O/chain_bench.txt 2>&1
 ( echo "# python bench.py --log-max-addr K --steps 20 --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary   (one MI355X, WORDSIZE 4)"; echo "log2(MAX_ADDR)  read_ms  rpw_ms  write_ms  ms_per_step  RAM ops/s  single-launch trace chains / fallbacks   mid-batch chains / fallbacks";
   for K in 12 13 14 15 16 18 20 21 22 24; do ST=20; [ $K -ge 22 ] && ST=4; python bench.py --log-max-addr $K --steps $ST --warmup 10 --no-cpu-baseline --no-kernel-timing --no-boundary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%6d %10.3f %9.3f %9.3f %10.3f %10.1f   %d/%d   %d/%d' % ($K, d['read_ms'], d['read_prepare_write_ms'], d['write_ms'], d['ms_per_step'], d['value'], d['trace_tail']['launches'], d['trace_tail']['fallbacks'], d['mid_chain']['launches'], d['mid_chain']['fallbacks']))"; done ) > $O/size_sweep.txt
-./tools/ntt_bench > $O/ntt_bench.txt 2>&1
-./tools/xcd_handoff > $O/xcd_handoff.txt 2>&1
-./tools/xcd_barrier > $O/xcd_barrier.txt 2>&1
-python tools/chain_ab.py 5 100 > $O/chain_ab.txt 2>&1
+./tools/fft_bench > $O/fft_bench.txt 2>&1
 python tools/chain_n.py > $O/chain_n.txt 2>&1
 FHERAM_SAFE=1 python bench.py --no-cpu-baseline > $O/bench_safe.json 2> $O/bench_safe.err
 FHERAM_PRE_INV=2 python bench.py --no-cpu-baseline > $O/bench_event_fork.json 2> $O/bench_event_fork.err

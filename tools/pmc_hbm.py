@@ -65,25 +65,20 @@ out = {"calibration": calib,
 
 
 def dominant(kern):
-    """The dominant kernel shape = one fused trace step over 256 ciphertexts.  Round 4: it runs inside k_keyswitch_chain<3,SK,3,3>
-    (the write's side-stream chain: 6 steps per launch at 2^18; PMC_CHAIN_STEPS overrides) and inside k_read_chain / k_write_chain
-    behind / in front of the products; the steps of a chain hand over through LDS and registers, so a launch reads its int32
-    input once, its keys (one per step) and writes its int32 output once: everything else stays on the CU."""
-    import os
-    steps = float(os.environ.get("PMC_CHAIN_STEPS", "6"))
-    for pat in ("k_keyswitch_chain<3, 4, 3, 3>", "k_keyswitch_chain<3, 5, 3, 3>", "k_keyswitch_chain<3, 4, 3"):
-        cand = [(k, e) for k, e in kern.items() if pat in k and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e
-                and int(k.split("grid_threads=")[1]) >= 65536]
+    """The dominant kernel = k_read_chain (a row's products of coordinate 0 + its alone packer levels as one launch, one workgroup
+    per row): the launch with the largest share of GPU time.  Its steps hand over through LDS and registers, so a launch reads its
+    int32 input once, its prepared operands (one GGSW digit per product, one key per trace step) and writes its int32 output once."""
+    for pat in ("k_read_chain<4, 4>", "k_read_chain<5, 4>", "k_write_chain<4, 4>"):
+        cand = [(k, e) for k, e in kern.items() if pat in k and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e]
         if cand:
             k, e = max(cand, key=lambda ke: ke[1]["launches"])
             blocks = int(k.split("grid_threads=")[1]) // 512
-            return {"kernel": k, "launches": e["launches"], "ciphertexts_per_step": blocks, "steps_per_launch": steps,
-                    "intermediate_form": "none in memory: the steps of a chain hand over through LDS and registers (ks_trace_l)",
-                    "read_bytes_per_step": e["read_bytes_per_launch"] / steps, "write_bytes_per_step": e["write_bytes_per_launch"] / steps,
-                    "hbm_bytes_per_launch": (e["read_bytes_per_launch"] + e["write_bytes_per_launch"]) / steps,
-                    "note": "hbm_bytes_per_launch is per STEP (one trace step over all ciphertexts = what bench.py's roofline calls a launch): "
-                            "the launch's bytes / its steps; compulsory per launch for the device layout: 2 x 98 304 B per ciphertext (int32 "
-                            "in and out) + 786 432 B of key per step"}
+            return {"kernel": k, "launches": e["launches"], "ciphertexts_per_launch": blocks,
+                    "read_bytes_per_launch": e["read_bytes_per_launch"], "write_bytes_per_launch": e["write_bytes_per_launch"],
+                    "hbm_bytes_per_launch": e["read_bytes_per_launch"] + e["write_bytes_per_launch"],
+                    "note": "compulsory per launch in the device layout: 98 304 B of int32 input per ciphertext (+ the same written where the "
+                            "products are in place), 98 304 B of output, 1.5 MiB per GGSW digit and 0.75 MiB per trace key ONCE; FETCH_SIZE "
+                            "also counts what the eight XCD L2s fetch from the Infinity Cache (each takes its own copy of the operands)"}
     return None
 
 
