@@ -1336,8 +1336,9 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 if constexpr (SK == 4) fold_limb4<SK>(od, acc[0], j); else fold_limb<SK>(od, ec, acc[0], j);
             }
-            // the next limbs' operands: their fetch runs under the first products (requested in front of the inverse transforms: 52-85 spilled
-            // registers, 27.0 against 25.3 us per step, profiles/r05_experiments.txt)
+            // the next limbs' operands: their fetch runs under the first products.  Requested in front of the inverse transforms (one, two or
+            // all three polynomials, 0 - 52 spilled registers) the step is 0.7 - 7 % SLOWER: the wait wave 0's stamps show is covered by
+            // the SIMD's other wave (profiles/r05_experiments.txt)
             if (j >= 2) fetch(j - 2, co, 0, SX);
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         }
