@@ -119,7 +119,7 @@ struct fheram_ctx {
     uint64_t mid_launches = 0, mid_launch_mark = 0;
     unsigned mid_fb_mark = 0;
     int mid_bad_windows = 0, mid_saved = 0;          // auto-disable of the single-launch mid chains: consecutive bad windows; the setting to come back to
-    uint64_t mid_off_at = 0, mid_disabled_count = 0; // launch count when it was switched off; times it has been
+    uint64_t mid_window_cts = 0, mid_disabled_count = 0; // ciphertexts launched in the current window of 64 launches; times the path has been switched off
     unsigned mid_off_ops = 0;                        // ops since then (re-armed after 256)
     unsigned* h_mid_fb = nullptr;      // pinned, device-visible: ciphertexts redone, [0] main stream, [16] side stream
     unsigned* d_mid_sync[2] = {nullptr, nullptr};   // [64 groups][32] + [_, ciphertexts redone]: main / side stream

@@ -42,7 +42,8 @@ struct fheram_group {
     // uploaded again (fheram_group_ram_upload resets every shard).  Errors found BEFORE anything is enqueued (the reference's
     // asserts: wrong state, foreign address, missing keys) are checked on the calling thread for every shard and poison nothing.
     bool poisoned = false;
-    std::vector<char> peer_direct;     // [shard] 1: the self-test copy shard <-> root went through (fheram_group_peer_info)
+    std::vector<char> peer_direct;     // [shard] 1: peer access ENABLED in both directions between the shard's device and the root's (or the same device); the self-test copy went through either way (fheram_group_peer_info)
+    std::vector<char> peer_enabled;    // [shard] result of hipDeviceEnablePeerAccess in both directions
     int root = 0;
     std::string err;
 
@@ -123,7 +124,10 @@ int group_precheck(fheram_group* g, const fheram_group_addr* ga, bool want_state
 int group_poison(fheram_group* g, int rc) {
     if (rc == FHERAM_OK) return rc;
     g->poisoned = true;
+    int dev_before = 0;
+    (void)hipGetDevice(&dev_before);
     for (fheram_ctx* c : g->ctx) { hipSetDevice(c->device); write_side_abort(c); }
+    (void)hipSetDevice(dev_before);   // the caller's current device is the caller's
     g->err += " [group poisoned: upload the rows again]";
     return rc;
 }
@@ -190,7 +194,7 @@ int group_write_job(fheram_group* g, const fheram_group_addr* ga, int i) {
     // second rendezvous: nobody touches its rows before EVERY shard has its ct_lo on the way — a shard that failed up to here
     // leaves all rows as they were (the root included)
     g->ready.fetch_add(1, std::memory_order_release);
-    if (!await_count(g, g->ready, g->n())) { write_side_abort(c); return fail(c, FHERAM_ERR_DEVICE, "a shard failed before the rows were written: no row has been changed"); }
+    if (!await_count(g, g->ready, g->n())) { write_side_abort(c); return fail(c, FHERAM_ERR_DEVICE, "a shard failed before the rows were written: the rows are unchanged, but the tree top and the write state have been consumed — upload the RAM again"); }
     rc = write_rows(c, addr);                                             // write_mid_step on the local rows, write_last_step
     if (rc != FHERAM_OK) return bail(rc);
     if (hipGetLastError() != hipSuccess) return bail(fail(c, FHERAM_ERR_DEVICE, "launch failure in write_rows"));
@@ -234,6 +238,7 @@ int fheram_group_create(const fheram_params* p, const int* devices, int n_device
     }
     g->ev_part.assign(n_devices, nullptr);
     g->ev_ctlo.assign(n_devices, nullptr);
+    g->peer_enabled.assign(n_devices, 0);
     for (int i = 0; i < n_devices; i++) {
         // ev_part[i] lives on shard i's device (recorded there), ev_ctlo[i] on the root's (recorded on the root's stream)
         hipError_t e = hipSetDevice(devices[i]);
@@ -243,17 +248,22 @@ int fheram_group_create(const fheram_params* p, const int* devices, int n_device
         if (e != hipSuccess) { g_group_err = std::string("hipEventCreate: ") + hipGetErrorString(e); fheram_group_destroy(g); return FHERAM_ERR_DEVICE; }
         // direct peer access root <-> shard where the topology offers it (xGMI); without it hipMemcpyPeerAsync stages
         if (devices[i] != devices[g->root]) {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devices[g->root], devices[i]) == hipSuccess && can) {
-                hipSetDevice(devices[g->root]); (void)hipDeviceEnablePeerAccess(devices[i], 0);
-                hipSetDevice(devices[i]); (void)hipDeviceEnablePeerAccess(devices[g->root], 0);
-                (void)hipGetLastError();   // "already enabled" is fine
+            int can = 0, can_back = 0;
+            auto enabled = [](hipError_t e) { return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled; };
+            if (hipDeviceCanAccessPeer(&can, devices[g->root], devices[i]) == hipSuccess && can &&
+                hipDeviceCanAccessPeer(&can_back, devices[i], devices[g->root]) == hipSuccess && can_back) {
+                hipSetDevice(devices[g->root]); const bool a = enabled(hipDeviceEnablePeerAccess(devices[i], 0));
+                hipSetDevice(devices[i]); const bool b = enabled(hipDeviceEnablePeerAccess(devices[g->root], 0));
+                (void)hipGetLastError();
+                g->peer_enabled[i] = (a && b) ? 1 : 0;   // what fheram_group_peer_info reports: access ENABLED in both directions
             }
         }
     }
     // self-test of the exchange path: one copy shard -> root and one root -> shard per shard, checked word for word.  A pair that
     // cannot copy (no peer path, IOMMU / IPC restrictions) fails HERE, with the pair named, not in the middle of the first read.
     g->peer_direct.assign(n_devices, 1);
+    int dev_before = 0;
+    (void)hipGetDevice(&dev_before);   // the self-test moves the calling thread between devices: restored below
     {
         fheram_ctx* r = g->ctx[g->root];
         const size_t n_probe = 256;
@@ -261,8 +271,7 @@ int fheram_group_create(const fheram_params* p, const int* devices, int n_device
         for (int i = 0; i < n_devices; i++) {
             fheram_ctx* c = g->ctx[i];
             if (c == r) continue;
-            int can = 0;
-            g->peer_direct[i] = (devices[i] == devices[g->root]) ? 1 : ((hipDeviceCanAccessPeer(&can, devices[g->root], devices[i]) == hipSuccess && can) ? 1 : 0);
+            g->peer_direct[i] = (devices[i] == devices[g->root]) ? 1 : g->peer_enabled[i];
             for (size_t k = 0; k < n_probe; k++) pat[k] = (int32_t)(0x5EED0000u + (unsigned)i * 4096u + (unsigned)k);
             hipError_t e = hipSetDevice(c->device);
             if (e == hipSuccess) e = hipMemcpy(c->d_part, pat.data(), n_probe * 4, hipMemcpyHostToDevice);
@@ -276,11 +285,13 @@ int fheram_group_create(const fheram_params* p, const int* devices, int n_device
             if (e != hipSuccess || back != pat) {
                 g_group_err = "peer copy self-test failed between device " + std::to_string(devices[i]) + " (shard " + std::to_string(i) + ") and the root's device " +
                               std::to_string(devices[g->root]) + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string(": data mismatch"));
+                (void)hipSetDevice(dev_before);
                 fheram_group_destroy(g);
                 return FHERAM_ERR_DEVICE;
             }
         }
     }
+    (void)hipSetDevice(dev_before);
     for (int i = 0; i < n_devices; i++) {
         g->w.emplace_back(new fheram_group::Worker());
         g->w.back()->th = std::thread(worker_main, g->w.back().get(), devices[i]);

@@ -147,18 +147,19 @@ void fill_mid(fheram_ctx* c, MidArgs& ma, GlweRef src, GlweRef dst, int n, int g
     c->mid_launches++;
     // A context that keeps losing its CUs to others stops asking — for a while.  The fallback launch mirrors the number of
     // ciphertexts it had to redo into a pinned host word (read without a synchronisation: a stale value only delays the
-    // decision by a window); what is counted here are WINDOWS of 64 launches in which more than 16 launches' worth of
-    // ciphertexts (on average a quarter) were redone: one contended launch — up to 64 ciphertexts at once — no longer switches
-    // the path off, two bad windows in a row do, and 1024 launches later the single-launch form is tried again.
+    // decision by a window).  A WINDOW is 64 launches; it is bad when more than a quarter of the ciphertexts launched in it
+    // (counted, both streams) were redone.  One contended launch does not switch the path off, two bad windows in a row do
+    // (fheram_mid_state); 256 ops later (path.hpp) the single-launch form is tried again.
+    c->mid_window_cts += (uint64_t)(gx * gy);
     if (!c->mid_test && c->mid_launches - c->mid_launch_mark >= 64) {
         const unsigned fb = __atomic_load_n(c->h_mid_fb, __ATOMIC_RELAXED) + __atomic_load_n(c->h_mid_fb + 16, __ATOMIC_RELAXED);
         const unsigned redone = fb - c->mid_fb_mark;
-        const unsigned cts = (unsigned)(gx * gy);
-        const bool bad = redone > 16u * (cts ? cts : 1u) / 4u + 16u;   // more than a quarter of 64 launches' ciphertexts
+        const bool bad = (uint64_t)redone * 4u > c->mid_window_cts;
         c->mid_bad_windows = bad ? c->mid_bad_windows + 1 : 0;
-        if (c->mid && c->mid_bad_windows >= 2) { c->mid_saved = c->mid; c->mid = 0; c->mid_off_at = c->mid_launches; c->mid_disabled_count++; }
+        if (c->mid && c->mid_bad_windows >= 2) { c->mid_saved = c->mid; c->mid = 0; c->mid_disabled_count++; }
         c->mid_fb_mark = fb;
         c->mid_launch_mark = c->mid_launches;
+        c->mid_window_cts = 0;
     }
     ma.seq = c->mid_seq; ma.n = n; ma.n_ct = gx * gy; ma.gx = gx; ma.rot_mul = 0; ma.rot_base = 0;
     ma.give_up_at = c->mid_test ? n - 2 : -1;
