@@ -1,5 +1,6 @@
 """The C-ABI shared library loads and exports every symbol include/fheram.h declares
 (no compute calls: this runs on the CPU-only build box)."""
+import ctypes as C
 import os
 import re
 
@@ -98,3 +99,27 @@ def test_cpp_host_mirror_builds_and_links(tmp_path):
                            "-Wl,-rpath," + os.path.dirname(pkg.library_path())])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_config_defaults_and_environment_overrides(monkeypatch):
+    """fheram_config_default (include/fheram.h): the library defaults, then the FHERAM_* environment variables of the same names —
+    how the GPU suite forces every decomposition.  Pure host code: runs without a GPU."""
+    pkg = load_package()
+    L = pkg.library()
+    from fheram_amd.api import _CConfig, _CONFIG_FIELDS
+    for k in list(os.environ):
+        if k.startswith("FHERAM_") and k != "FHERAM_LIB":
+            monkeypatch.delenv(k)
+    cfg = _CConfig()
+    L.fheram_config_default(C.byref(cfg))
+    got = {f: getattr(cfg, f) for f in _CONFIG_FIELDS}
+    assert got == {"limb_split": 1, "fine_split": 1, "memo": 1, "pre_inv": 1, "tail": 1, "tail_test": 0, "mid": 2, "mid_test": 0, "chain": 1,
+                   "chain_y": 3, "pair_z": 1, "fuse": 1, "graph": 0, "safe": 0, "nco": 0, "reserved": 0}
+    for name, val, field, want in (("FHERAM_SAFE", "1", "safe", 1), ("FHERAM_CHAIN_Y", "0", "chain_y", 0), ("FHERAM_TAIL", "2", "tail_test", 1),
+                                   ("FHERAM_TAIL", "0", "tail", 0), ("FHERAM_MID", "2", "mid_test", 1), ("FHERAM_MID", "1", "mid", 1),
+                                   ("FHERAM_NCO", "2", "nco", 2), ("FHERAM_PRE_INV", "2", "pre_inv", 2), ("FHERAM_GRAPH", "1", "graph", 1),
+                                   ("FHERAM_FUSE", "0", "fuse", 0), ("FHERAM_MEMO", "0", "memo", 0), ("FHERAM_LIMB_SPLIT", "0", "limb_split", 0)):
+        monkeypatch.setenv(name, val)
+        L.fheram_config_default(C.byref(cfg))
+        assert getattr(cfg, field) == want, (name, val)
+        monkeypatch.delenv(name)
