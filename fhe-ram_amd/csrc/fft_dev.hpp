@@ -64,6 +64,30 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- a split barrier in LDS for the fences of a limb loop ------------------------------------------------------------------------
+// A workgroup barrier costs a chain step ~0.35 us (the waves wait for the slowest).  The fence in front of an inverse batch only
+// says "every wave has finished reading the previous batch's buffers across waves" — and the wave that gets there first has a fold,
+// operand loads and six polynomial products to do before it stores into those buffers again.  So: ARRIVE (one LDS add by lane 0)
+// behind the wave's last cross-wave load of a batch, WAIT (poll one LDS word) in front of the next batch's first store.  The
+// counter is dword 3 of twiddle slot 0 (never a twiddle: twpos >= 1; zeroed by the table copy, whose __syncthreads publishes it).
+// LDS operations of a wave execute in order, so the arrival is performed behind the loads it stands for.  The counter only grows,
+// and a wave arrives for batch m + 1 behind that batch's rendezvous barrier, which every wave reaches behind its own arrival for
+// batch m: arrivals come in rounds of eight, and "a multiple of eight" means "every wave has arrived for every batch so far" — no
+// state is carried between calls.  (The rendezvous inside a transform stays the hardware barrier: polling it was measured slower.)
+__device__ __forceinline__ unsigned sb_addr(const double* tw) { return (unsigned)(size_t)tw + 12u; }
+__device__ __forceinline__ bool sb_lane0() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u; }
+__device__ __forceinline__ void sb_arrive_free(unsigned a) {
+    if (sb_lane0()) asm volatile("ds_add_u32 %0, %1" : : "v"(a), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void sb_wait_free(unsigned a) {
+    for (;;) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+        if ((__builtin_amdgcn_readfirstlane(v) & 7u) == 0u) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // Cooley-Tukey butterfly: (u, v) <- (u + w v, u - w v), 6 FP64 instructions (the second output as 2u - first)
 __device__ __forceinline__ void bf(d2& u, d2& v, const d2 w) {
     double lr = __builtin_fma(w.x, v.x, u.x);
@@ -273,12 +297,14 @@ __device__ __forceinline__ void fft_fwd_skew(double (&x)[B][E], const double* tw
     d2 y[B][4];
     Tw5 t0; Tw7 t1, t2;
     tw_p0(t0, tw, xa);
-#pragma unroll
-    for (int b = 0; b < B; b++) { nat_in(y[b], x[b]); f_pass3(y[b], t0); }
+    nat_in(y[0], x[0]); f_pass3(y[0], t0);
     tw_p1(t1, tw, xa);
-    lds_barrier();
+    lds_barrier();                       // every earlier access of the workgroup to these buffers is done: stores may cross waves now
 #pragma unroll
-    for (int b = 0; b < B; b++) x0a_w(y[b], reinterpret_cast<d2*>(d[b]), xa);
+    for (int b = 0; b < B; b++) {
+        if (b > 0) { nat_in(y[b], x[b]); f_pass3(y[b], t0); }
+        x0a_w(y[b], reinterpret_cast<d2*>(d[b]), xa);
+    }
     lds_barrier();
 #pragma unroll
     for (int b = 0; b < B; b++) x0b_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
@@ -297,7 +323,9 @@ __device__ __forceinline__ void fft_fwd_skew(double (&x)[B][E], const double* tw
 // out: x[b][k] = coefficient tid + T k, ROUNDED to the nearest integer (an exact integer-valued double)
 // FENCE: workgroup barrier in front of the first LDS write.  Needed when another wave may still be reading this buffer
 // across waves (the natural side of exchange 0 of the previous inverse transform in the SAME buffer, or a kernel's own gathers).
-template <int B, bool FENCE, bool ROUND = true>
+// FENCE 0: nothing; 1: workgroup barrier; 2: wait until every wave has finished the cross-wave reads of the previous FENCE-2 batch
+// (the batches of one limb loop: same buffers, nothing but register work and operand loads in between), and say so at the end.
+template <int B, int FENCE, bool ROUND = true>
 __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw_, double* const (&d)[B], int tid) {
     const d2* tw = reinterpret_cast<const d2*>(tw_);
     const XAddr xa = xaddr(tid);
@@ -306,7 +334,8 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
     tw_p2(t2, tw, xa);
 #pragma unroll
     for (int b = 0; b < B; b++) dom_in(y[b], x[b]);
-    if constexpr (FENCE) lds_barrier();
+    if constexpr (FENCE == 1) lds_barrier();
+    if constexpr (FENCE == 2) sb_wait_free(sb_addr(tw_));
 #pragma unroll
     for (int b = 0; b < B; b++) {
         i_pass4(y[b], t2);
@@ -326,6 +355,7 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
     for (int b = 0; b < B; b++) x0a_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
 #pragma unroll
     for (int b = 0; b < B; b++) { i_pass3(y[b], t0); nat_out<ROUND>(y[b], x[b]); }
+    if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
 }
 
 // ---- the interface the kernels use (B polynomials at a time; data = B consecutive exchange buffers of LDS_DATA doubles) --------
@@ -340,13 +370,22 @@ __device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, dou
 template <int B, bool FENCE = true, bool PRE = true>
 __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, double* data, int tid) {
     static_assert(B >= 1 && B <= 2, "one or two polynomials");
-    if constexpr (B == 1) { double* const d[1] = {data}; fft_inv_skew<1, FENCE>(x, tw, d, tid); }
-    else { double* const d[2] = {data, data + LDS_DATA}; fft_inv_skew<2, FENCE>(x, tw, d, tid); }
+    if constexpr (B == 1) { double* const d[1] = {data}; fft_inv_skew<1, FENCE ? 1 : 0>(x, tw, d, tid); }
+    else { double* const d[2] = {data, data + LDS_DATA}; fft_inv_skew<2, FENCE ? 1 : 0>(x, tw, d, tid); }
 }
 template <bool FENCE = true, bool PRE = true>
 __device__ __forceinline__ void ntt_inv2_skew(double (&x)[2][E], const double* tw, double* d0, double* d1, int tid) {
     double* const d[2] = {d0, d1};
-    fft_inv_skew<2, FENCE>(x, tw, d, tid);
+    fft_inv_skew<2, FENCE ? 1 : 0>(x, tw, d, tid);
+}
+// the pairs of one limb loop (same two buffers every time, register work and operand loads in between): fenced by the free counter
+__device__ __forceinline__ void ntt_inv2_loop(double (&x)[2][E], const double* tw, double* d0, double* d1, int tid) {
+    double* const d[2] = {d0, d1};
+    fft_inv_skew<2, 2>(x, tw, d, tid);
+}
+__device__ __forceinline__ void ntt_inv1_loop(double (&x)[1][E], const double* tw, double* d0, int tid) {
+    double* const d[1] = {d0};
+    fft_inv_skew<1, 2>(x, tw, d, tid);
 }
 __device__ __forceinline__ void ntt_fwd3_skew(double (&x)[3][E], const double* tw, double* data, int tid) { ntt_fwd<3>(x, tw, data, tid); }
 

@@ -1136,9 +1136,6 @@ __device__ __forceinline__ void fold_limb4(double (&od)[E], const double (&acc)[
     double ec[E];
     fold_limb<SK>(od, ec, acc, j);
 }
-#ifndef FK_Z_SKEW_ODD
-#define FK_Z_SKEW_ODD 0   // ks_trace_l, 5-limb keys: the skewed pair of inverse transforms (six spilled registers with it, none without)
-#endif
 
 // ---------------------------------------------------------------------------------------
 // ks_trace_l (round 4): ks_trace_z with the hand-over between the steps of a chain through LDS and registers.  Producer and
@@ -1287,13 +1284,12 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
             __builtin_amdgcn_sched_barrier(0);
             YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
             if constexpr (NB == 2) {
-                if constexpr (FK_Z_SKEW_ODD) ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);   // (5-limb keys: six spilled registers with the skewed pair, none without)
-                else ntt_inv<2, true, false>(acc, tw, data, tid);
+                ntt_inv2_loop(acc, tw, data, data + LDS_DATA, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
                 fold_limb<SK>(od, ec, acc[NB - 1], j - 1);
             } else {
-                ntt_inv<1, true, false>(acc, tw, data, tid);
+                ntt_inv1_loop(acc, tw, data, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 fold_limb<SK>(od, ec, acc[0], j);
             }
@@ -1327,12 +1323,12 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
             __builtin_amdgcn_sched_barrier(0);
             YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
             if (two) {
-                ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);
+                ntt_inv2_loop(acc, tw, data, data + LDS_DATA, tid);   // (fenced against the previous pair's cross-wave readers by the free counter, not by a barrier)
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 if constexpr (SK == 4) { fold_limb4<SK>(od, acc[0], j); fold_limb4<SK>(od, acc[1], j - 1); }
                 else { fold_limb<SK>(od, ec, acc[0], j); fold_limb<SK>(od, ec, acc[1], j - 1); }
             } else {
-                ntt_inv<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
+                ntt_inv1_loop(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
                 YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
                 if constexpr (SK == 4) fold_limb4<SK>(od, acc[0], j); else fold_limb<SK>(od, ec, acc[0], j);
             }
@@ -1694,7 +1690,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
 #pragma unroll
         for (int r = 0; r < SX; r++) mac_regs(acc[1], xh[r], g[r]);
         __builtin_amdgcn_sched_barrier(0);
-        ntt_inv2_skew<true, false>(acc, tw, data, data + LDS_DATA, tid);
+        ntt_inv2_loop(acc, tw, data, data + LDS_DATA, tid);
         fold_limb<SK>(od, ec, acc[0], j);
         fold_limb<SK>(od, ec, acc[1], j - 1);
         if (j >= 2) {
@@ -1710,7 +1706,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
         for (int k = 0; k < E; k++) acc[0][k] = 0.0;
 #pragma unroll
         for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
-        ntt_inv<1, true, false>(acc, tw, data, tid);
+        ntt_inv1_loop(acc, tw, data, tid);
         fold_limb<SK>(od, ec, acc[0], 0);
     }
 #pragma unroll

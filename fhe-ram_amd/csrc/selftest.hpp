@@ -55,11 +55,11 @@ __global__ __launch_bounds__(T) void k_selftest_convolve(const int32_t* __restri
     if constexpr (SINGLE) {
         double* const d0[1] = {data};
         double* const d1[1] = {data + LDS_DATA};
-        fft_inv_skew<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, d0, tid);
-        fft_inv_skew<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[1]), tw, d1, tid);
+        fft_inv_skew<1, 1, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, d0, tid);
+        fft_inv_skew<1, 1, false>(*reinterpret_cast<double(*)[1][E]>(&acc[1]), tw, d1, tid);
     } else {
         double* const d[2] = {data, data + LDS_DATA};
-        fft_inv_skew<2, true, false>(acc, tw, d, tid);
+        fft_inv_skew<2, 1, false>(acc, tw, d, tid);
     }
 #pragma unroll
     for (int b = 0; b < 2; b++)

@@ -50,9 +50,9 @@ __global__ __launch_bounds__(T) void k_conv(const int* a, const int* g, double* 
     if (MODE == 1) {
         double* const d0[1] = {data};
         double* const d1[1] = {data + LDS_DATA};
-        fft_inv_skew<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, d0, tid);
-        fft_inv_skew<1, true, false>(*reinterpret_cast<double(*)[1][E]>(&acc[1]), tw, d1, tid);
-    } else { double* const d[2] = {data, data + LDS_DATA}; fft_inv_skew<2, true, false>(acc, tw, d, tid); }
+        fft_inv_skew<1, 1, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, d0, tid);
+        fft_inv_skew<1, 1, false>(*reinterpret_cast<double(*)[1][E]>(&acc[1]), tw, d1, tid);
+    } else { double* const d[2] = {data, data + LDS_DATA}; fft_inv_skew<2, 1, false>(acc, tw, d, tid); }
     for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) out[(long)b * N + tid + T * k] = acc[b][k];
 }
 
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(T, T / 256) void k_time(const double* tw_g, double*
         if (MODE == 3) ntt_fwd<3>(x, tw, data, tid);
         if (MODE == 11) ntt_inv<1, true>(*reinterpret_cast<double(*)[1][E]>(&x[0]), tw, data, tid);
         if (MODE == 12) ntt_inv<2, true>(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, tid);
-        if (MODE == 13) fft_inv_skew<3, true>(x, tw, d3, tid);
+        if (MODE == 13) fft_inv_skew<3, 1>(x, tw, d3, tid);
+        if (MODE == 22) ntt_inv2_loop(*reinterpret_cast<double(*)[2][E]>(&x[0]), tw, data, data + LDS_DATA, tid);
         for (int b = 0; b < 3; b++) for (int k = 0; k < E; k++) x[b][k] *= 0.001;
     }
     double s = 0;
@@ -143,5 +144,6 @@ int main() {
     timeit(k_time<11>, "inverse, 1", tw, sink, 256, 1);
     timeit(k_time<12>, "inverse, 2 half a phase apart", tw, sink, 256, 2);
     timeit(k_time<13>, "inverse, 3 half a phase apart", tw, sink, 256, 3);
+    timeit(k_time<22>, "inverse, 2, fenced by the free counter", tw, sink, 256, 2);
     return bad ? 1 : 0;
 }
