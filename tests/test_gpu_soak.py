@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def test_soak_every_launch_decomposition_reproducible_and_exact(po):
     import soak_gpu
-    rounds, checks = soak_gpu.main(seconds=25, seed=20261003)
+    rounds, checks = soak_gpu.main(seconds=12, seed=20261003)
     assert rounds >= 20 and checks >= 40
 
 
@@ -19,7 +19,7 @@ def test_soak_whole_ram_flows_over_random_shapes(po):
     plans and addresses through read / read_prepare_write / write / read-back, every output and the whole state
     bit-identical to the oracle's."""
     import soak_flow_gpu
-    assert soak_flow_gpu.main(seconds=25, seed=20261004) >= 2
+    assert soak_flow_gpu.main(seconds=15, seed=20261004) >= 2
 
 
 def test_soak_single_launch_trace_chain(po):
@@ -27,7 +27,7 @@ def test_soak_single_launch_trace_chain(po):
     launch each (in-kernel hand-offs), three times each (must reproduce itself) and against the oracle, while another
     host thread fills the chip from a second context."""
     import soak_tail_gpu
-    rounds, st = soak_tail_gpu.main(seconds=15, seed=20261005)
+    rounds, st = soak_tail_gpu.main(seconds=8, seed=20261005)
     assert rounds >= 5 and st["launches"] >= 3 * rounds and st["fallbacks"] <= st["launches"]
 
 
@@ -36,7 +36,7 @@ def test_soak_mid_batch_chains(po):
     in-kernel hand-offs, giving up per ciphertext) while a second context competes for the CUs: reproducible, exact, and
     whatever gave up was redone."""
     import soak_tail_gpu
-    rounds, st = soak_tail_gpu.main(seconds=15, seed=20261006, batches=(9, 64))
+    rounds, st = soak_tail_gpu.main(seconds=8, seed=20261006, batches=(9, 64))
     assert rounds >= 5 and st["launches"] >= 3 * rounds
 
 
