@@ -101,6 +101,18 @@ public:
         int rc = fheram_ctx_create(&params.p, device, &ctx_);
         if (rc != FHERAM_OK) throw Error(rc, fheram_last_error(nullptr));
     }
+    // explicit execution switches (include/fheram.h: fheram_config; start from default_config() and change what differs)
+    Ram(const Parameters& prm, const fheram_config& cfg, int device = 0) : params(prm) {
+        int rc = fheram_ctx_create_cfg(&params.p, device, 0, 1, &cfg, &ctx_);
+        if (rc != FHERAM_OK) throw Error(rc, fheram_last_error(nullptr));
+    }
+    static fheram_config default_config() { fheram_config c; fheram_config_default(&c); return c; }
+    fheram_config config() const {                                                  // the switches in effect
+        fheram_config c;
+        int rc = fheram_ctx_config(ctx_, &c);
+        if (rc != FHERAM_OK) throw Error(rc, "fheram_ctx_config");
+        return c;
+    }
     static Ram new_from_ram_params(size_t word_size, const std::vector<uint8_t>& decomp_n, size_t max_addr, int device = 0) {   // ram.rs:72
         return Ram(Parameters(word_size, decomp_n, max_addr), device);
     }

@@ -14,8 +14,13 @@ int main() {
     if (p.max_addr() != (1u << 14) || p.word_size() != 4 || p.basek() != 17) return 2;   // parameters.rs:11-21
     fheram::Parameters rd = fheram::Parameters::readme();                                    // README.md:20-33
     if (rd.max_addr() != (1u << 18) || rd.k_glwe_pt() != 9 || rd.p.k_evk_trace != 5 * 17) return 2;
+    {   // execution switches: library defaults (pure host code: runs without a GPU)
+        const fheram_config c = fheram::Ram::default_config();
+        if (!c.fuse || !c.tail || c.chain_y != 3 || c.reserved != 0) return 6;
+    }
     try {
         fheram::Ram ram = fheram::Ram::new_from_ram_params(4, {3, 3, 3, 3}, 1 << 12);
+        if (ram.config().fuse != fheram::Ram::default_config().fuse) return 6;
         fheram::EvaluationKeysPrepared keys;
         fheram::Address addr;
         try { ram.read(addr, keys); return 3; }                      // no keys, empty RAM: must throw
