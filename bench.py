@@ -124,6 +124,21 @@ def pmc_traffic(kernel_prefix):
     return None if best is None else best["read_bytes_per_launch"] + best["write_bytes_per_launch"]
 
 
+def pmc_valu_busy(kernel_label):
+    """VALU busy fraction of a kernel from the committed SQ-counter summary (None if absent)"""
+    path = os.path.join(ROOT, "profiles", "r05_pmc_sq_summary.txt")
+    if not os.path.exists(path):
+        return None
+    import re
+    name = kernel_label.split("<")[0]
+    for line in open(path):
+        if ("fk::" + name + "<") in line:
+            m = re.search(r"ACTIVE_INST_VALU=[0-9.e+]+\(([0-9.]+)%\)", line)
+            if m:
+                return 2 * float(m.group(1)) / 100.0
+    return None
+
+
 def make_inputs(p, ws, s_evk, n_digits, rows_local, seed_keys=1234, seed_rows=4321):
     """The synthetic inputs of a run: evaluation keys, address digits, RAM rows, the words of the write.  ONE function for the
     GPU legs and the oracle leg (identical inputs, examples/fhe-ram.rs:98-115 checks the result it has just timed)."""
@@ -725,6 +740,8 @@ def main():
             lds_bytes = n_tr * 2 * 2 * 32768 + n_tr * 13 * 16 * 512        # two exchanges (write + read) + 13 twiddle reads of 16 B per thread
             opnd_bytes = n_mac * 32768
             dom["pipes"] = {"what": "per workgroup (= per CU: one ciphertext each) and launch, from the kernel's structure; rates against the CU's own peaks at the clock the stamps show (2.19 GHz)",
+                            "valu_busy_frac_pmc": pmc_valu_busy(dom["kernel"]),
+                            "valu_busy_source": "profiles/r05_pmc_sq_summary.txt: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of this kernel x 2 waves per SIMD (a separate rocprofv3 --pmc pass of this command): the share of time the vector ALU issues ANY instruction (FP64, swap rounds, address and digit arithmetic)",
                             "transforms": n_tr, "polynomial_macs": n_mac,
                             "fp64_busy_frac": dom["frac"],
                             "lds_bytes": lds_bytes, "lds_GBs_per_cu": lds_bytes / t_launch / 1e9, "lds_peak_GBs_per_cu": "~85 B/clk stores, 256 B/clk loads (MI355X_MICROARCH.md LDS table): 186 / 560",
