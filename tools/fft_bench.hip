@@ -82,19 +82,40 @@ __global__ __launch_bounds__(T, T / 256) void k_time(const double* tw_g, double*
     sink[blockIdx.x * T + threadIdx.x] = s;
 }
 
+// The same single transforms from TWO independent workgroups per CU (<= 128 registers, one exchange buffer each): what phase
+// diversity between the waves of a SIMD would be worth (the evaluator's kernels cannot run this way: they need > 128 registers).
+template <int MODE>
+__global__ __launch_bounds__(T, 2) void k_time_occ2(const double* tw_g, double* sink, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = vt((int)threadIdx.x);
+    load_twiddles(tw, tw_g, tid);
+    double x[1][E];
+    for (int k = 0; k < E; k++) x[0][k] = (double)((tid * 8 + k) & 1023);
+    for (int r = 0; r < reps; r++) {
+        if (MODE == 1) ntt_fwd<1>(x, tw, data, tid);
+        if (MODE == 11) ntt_inv<1, true>(x, tw, data, tid);
+        for (int k = 0; k < E; k++) x[0][k] *= 0.001;
+    }
+    double s = 0;
+    for (int k = 0; k < E; k++) s += x[0][k];
+    sink[blockIdx.x * T + threadIdx.x] = s;
+}
+
 static void exact_negacyclic(const int* a, const int* g, long long* c) {
     std::vector<__int128> t(2 * N, 0);
     for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) t[i + j] += (__int128)a[i] * g[j];
     for (int i = 0; i < N; i++) c[i] = (long long)(t[i] - t[i + N]);
 }
 template <typename K>
-static void timeit(K kern, const char* name, const double* tw, double* sink, int blocks, double per) {
+static void timeit(K kern, const char* name, const double* tw, double* sink, int blocks, double per, size_t lds_bytes = LDS_BYTES) {
     const int reps = 2000;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), LDS_BYTES, 0, tw, sink, 10);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), lds_bytes, 0, tw, sink, 10);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), LDS_BYTES, 0, tw, sink, reps);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), lds_bytes, 0, tw, sink, reps);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-40s blocks=%4d: %7.3f us per call, %7.3f us per polynomial transform per CU\n", name, blocks, ms * 1e3 / reps, ms * 1e3 / reps / per);
@@ -145,5 +166,10 @@ int main() {
     timeit(k_time<12>, "inverse, 2 half a phase apart", tw, sink, 256, 2);
     timeit(k_time<13>, "inverse, 3 half a phase apart", tw, sink, 256, 3);
     timeit(k_time<22>, "inverse, 2, fenced by the free counter", tw, sink, 256, 2);
+    const size_t lds1 = (size_t)(LDS_TW + LDS_DATA) * sizeof(double);   // 69 632 B: two workgroups fit a CU's 160 KB
+    timeit(k_time_occ2<1>, "forward, 1, ONE workgroup per CU (same kernel)", tw, sink, 256, 1, lds1);
+    timeit(k_time_occ2<1>, "forward, 1, TWO workgroups per CU", tw, sink, 512, 2, lds1);
+    timeit(k_time_occ2<11>, "inverse, 1, ONE workgroup per CU (same kernel)", tw, sink, 256, 1, lds1);
+    timeit(k_time_occ2<11>, "inverse, 1, TWO workgroups per CU", tw, sink, 512, 2, lds1);
     return bad ? 1 : 0;
 }
