@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fk {
 
@@ -355,6 +356,89 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
     for (int b = 0; b < B; b++) x0a_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
 #pragma unroll
     for (int b = 0; b < B; b++) { i_pass3(y[b], t0); nat_out<ROUND>(y[b], x[b]); }
+    if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
+}
+
+// ---- ONE inverse transform with work of the caller's between its phases -------------------------------------------------------------
+// hook(std::integral_constant<int, s>) is called at three points where the wave would otherwise wait for LDS: s = 0 behind the
+// issue of exchange 1, s = 1 behind the stores of exchange 0 (in front of the rendezvous), s = 2 behind the issue of its loads.
+// The callers stream prepared operands through there (global loads requested, multiply-accumulates of the NEXT output limb
+// taken): the operand stream of a chain step — 0.75 to 1.5 MB per step through the CU's ~57 B/clk load path — then runs under the
+// transforms instead of beside them (tools/fft_bench.hip, k_stream: a transform pair with 192 KB requested in front of it takes
+// 3.19 us against 3.04 without the loads and 1.60 for the loads alone).
+#ifndef FK_HOOK_TW_LATE
+#define FK_HOOK_TW_LATE 1
+#endif
+template <int FENCE, bool ROUND = true, class Hook>
+__device__ __forceinline__ void fft_inv1_hooked(double (&x)[1][E], const double* tw_, double* d0, int tid, Hook&& hook) {
+    const d2* tw = reinterpret_cast<const d2*>(tw_);
+    d2* buf = reinterpret_cast<d2*>(d0);
+    const XAddr xa = xaddr(tid);
+    d2 y[4];
+    Tw7 t2, t1; Tw5 t0;
+    tw_p2(t2, tw, xa);
+    dom_in(y, x[0]);
+    if constexpr (FENCE == 1) lds_barrier();
+    if constexpr (FENCE == 2) sb_wait_free(sb_addr(tw_));
+    i_pass4(y, t2);
+    x1b_w(y, buf, xa); wave_lds_fence(); x1a_r(y, buf, xa);
+    if constexpr (!FK_HOOK_TW_LATE) tw_p1(t1, tw, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    hook(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FK_HOOK_TW_LATE) tw_p1(t1, tw, xa);   // (behind the hook: 20 registers fewer are live across it)
+    i_pass4(y, t1);
+    x0b_w(y, buf, xa);
+    if constexpr (!FK_HOOK_TW_LATE) tw_p0(t0, tw, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    hook(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    x0a_r(y, buf, xa);
+    if constexpr (FK_HOOK_TW_LATE) tw_p0(t0, tw, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    hook(std::integral_constant<int, 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    i_pass3(y, t0);
+    nat_out<ROUND>(y, x[0]);
+    if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
+}
+
+// ---- TWO inverse transforms half a phase apart with work of the caller's between their phases (six places) ------------------------------
+template <int FENCE, class Hook>
+__device__ __forceinline__ void fft_inv2_hooked(double (&x)[2][E], const double* tw_, double* d0, double* d1, int tid, Hook&& hook) {
+    const d2* tw = reinterpret_cast<const d2*>(tw_);
+    d2* const buf[2] = {reinterpret_cast<d2*>(d0), reinterpret_cast<d2*>(d1)};
+    const XAddr xa = xaddr(tid);
+    d2 y[2][4];
+    Tw7 t2, t1; Tw5 t0;
+    tw_p2(t2, tw, xa);
+    dom_in(y[0], x[0]); dom_in(y[1], x[1]);
+    if constexpr (FENCE == 1) lds_barrier();
+    if constexpr (FENCE == 2) sb_wait_free(sb_addr(tw_));
+#define FK_HOOK(s) __builtin_amdgcn_sched_barrier(0); hook(std::integral_constant<int, s>{}); __builtin_amdgcn_sched_barrier(0)
+    i_pass4(y[0], t2);
+    x1b_w(y[0], buf[0], xa); wave_lds_fence(); x1a_r(y[0], buf[0], xa);
+    tw_p1(t1, tw, xa);
+    FK_HOOK(0);
+    i_pass4(y[1], t2);
+    x1b_w(y[1], buf[1], xa); wave_lds_fence(); x1a_r(y[1], buf[1], xa);
+    FK_HOOK(1);
+    i_pass4(y[0], t1);
+    x0b_w(y[0], buf[0], xa);
+    tw_p0(t0, tw, xa);
+    FK_HOOK(2);
+    i_pass4(y[1], t1);
+    x0b_w(y[1], buf[1], xa);
+    FK_HOOK(3);
+    lds_barrier();
+    x0a_r(y[0], buf[0], xa);
+    x0a_r(y[1], buf[1], xa);
+    FK_HOOK(4);
+    i_pass3(y[0], t0); nat_out<true>(y[0], x[0]);
+    FK_HOOK(5);
+    i_pass3(y[1], t0); nat_out<true>(y[1], x[1]);
+#undef FK_HOOK
     if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
 }
 

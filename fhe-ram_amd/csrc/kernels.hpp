@@ -223,7 +223,12 @@ __device__ __forceinline__ void mac_poly(double (&acc)[E], const double (&x)[E],
     const double2* gp = reinterpret_cast<const double2*>(g);
 #pragma unroll
     for (int kk = 0; kk < E / 2; kk++) {
+#ifdef FK_NO_OPERANDS   // measurement only (wrong results): what the step costs without its operand stream
+        double2 v;
+        asm volatile("" : "=v"(v.x), "=v"(v.y));
+#else
         const double2 v = gp[kk * T + tid];
+#endif
         cmac(acc[2 * kk], acc[2 * kk + 1], x[2 * kk], x[2 * kk + 1], v.x, v.y);
     }
 }
@@ -231,6 +236,11 @@ __device__ __forceinline__ void mac_poly(double (&acc)[E], const double (&x)[E],
 // Prepared-operand registers of one polynomial (E/2 16-byte words per thread).
 struct OpRegs { double2 v[E / 2]; };
 __device__ __forceinline__ void load_ops(OpRegs& o, const double* __restrict__ g, int tid) {
+#ifdef FK_NO_OPERANDS
+#pragma unroll
+    for (int kk = 0; kk < E / 2; kk++) asm volatile("" : "=v"(o.v[kk].x), "=v"(o.v[kk].y));
+    return;
+#endif
 #if FK_SADDR
     // Every operand polynomial of a launch is addressed as (wave-uniform base) + (lane offset): the base — key / GGSW
     // pointer, limb, column, kk * 8 KiB — lives in scalar registers and is advanced by scalar adds, the lane offset is ONE
@@ -255,6 +265,12 @@ __device__ __forceinline__ void load_ops(OpRegs& o, const double* __restrict__ g
 #pragma unroll
     for (int kk = 0; kk < E / 2; kk++) o.v[kk] = gp[kk * T + tid];
 #endif
+}
+// Makes the compiler materialise x here (no instruction): code motion passes sink a multiply-accumulate towards its first use, which
+// may lie behind the NEXT operands' requests — and then its wait covers those requests as well.
+__device__ __forceinline__ void pin_regs(double (&x)[E]) {
+#pragma unroll
+    for (int k = 0; k < E; k++) asm volatile("" : "+v"(x[k]));
 }
 __device__ __forceinline__ void mac_regs(double (&acc)[E], const double (&x)[E], const OpRegs& o) {
 #pragma unroll
@@ -308,6 +324,30 @@ constexpr int BF = FK_BF, BI = FK_BI;
 static_assert(BF <= BMAX && BI <= BMAX, "LDS holds BMAX exchange buffers");
 
 // forward transform of S polynomials, BF at a time
+#ifndef FK_KS_STREAM
+#define FK_KS_STREAM 1    // ks_trace_l (even limb counts): the operand stream under the pairs of inverse transforms (fft_inv2_hooked)
+#endif
+#ifndef FK_KS_WINDOW
+#define FK_KS_WINDOW 2
+#endif
+#ifndef FK_KS_EARLY
+#define FK_KS_EARLY 0     // ks_trace_l (even limb counts): the next pair's first operands requested in front of the inverse transforms
+#endif
+#ifndef FK_KS_SINGLE
+#define FK_KS_SINGLE 0    // ks_trace_l (even limb counts): single inverse transforms with the next limb's operands in flight under them
+#endif
+#ifndef FK_EP_STREAM
+#define FK_EP_STREAM 1    // ep_step_r: the operand stream runs under the inverse transforms (fft_inv1_hooked)
+#endif
+#ifndef FK_EP_EARLY
+#define FK_EP_EARLY 0     // ep_step_r: the next limb's first three operands requested in front of the inverse transform
+#endif
+#ifndef FK_EP_PARK
+#define FK_EP_PARK 1      // ... and the column's running sum V is parked in LDS between the folds
+#endif
+#ifndef FK_EP_WINDOW
+#define FK_EP_WINDOW 2    // operand polynomials in flight (16 registers each)
+#endif
 #ifndef FK_FWD_SKEW
 #define FK_FWD_SKEW 1   // ks_trace_l: the three forward transforms half a phase apart (ntt_fwd3_skew): trace step 35.8 -> 35.6 us, step 2.198 -> 2.18 ms; the same in the products: +1 % per product, not used there
 #endif
@@ -1225,6 +1265,17 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         for (int r = 0; r < SX; r++)
             if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
     };
+    constexpr bool STREAM = FK_KS_STREAM && !(SK & 1);
+    constexpr int KW = FK_KS_WINDOW, NQ = 2 * SX;
+    [[maybe_unused]] OpRegs w[STREAM ? KW : 1];
+    [[maybe_unused]] double accn[2][E];
+    // operand q of the pair of output limbs (j, j - 1) of column co_: limb j - q / SX, digit row q % SX
+    [[maybe_unused]] auto kopnd = [&](int co_, int j_, int q) { return ka.key + (long)(((q % SX) * SK + (j_ - q / SX)) * 2 + co_) * N; };
+    if constexpr (STREAM) {
+#pragma unroll
+        for (int i = 0; i < KW; i++) load_ops(w[i], kopnd(1, SK - 1, i), tid);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     YSTAMP(2);
     fwd_all<SX, 0, true>(xh, tw, data, tid);   // its first exchange starts with a barrier: every gather above is done before the buffers are overwritten
     YSTAMP(3);
@@ -1236,6 +1287,21 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
     double y1n[E];   // column 1's output Y, on its way to buffer 2 (the next step's mask staging)
 #pragma unroll
     for (int k = 0; k < E; k++) y1n[k] = 0.0;
+    if constexpr (STREAM) {   // the first pair's products: nothing to run under yet (their first KW operands arrived during the forward transforms)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int k = 0; k < E; k++) accn[b][k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            mac_regs(accn[q / SX], xh[q % SX], w[q % KW]);
+            pin_regs(accn[q / SX]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + KW < NQ) load_ops(w[q % KW], kopnd(1, SK - 1, q + KW), tid);
+            else load_ops(w[q % KW], kopnd(SK >= 4 ? 1 : 0, SK >= 4 ? SK - 3 : SK - 1, q + KW - NQ), tid);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
     for (int ci = 0; ci < 2; ci++) {   // (unrolled: what is live across a column differs between the two)
         const int co = 1 - ci;
@@ -1259,7 +1325,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         }
 #pragma unroll
         for (int k = 0; k < E; k++) ec[k] = 0.0;
-        fetch(SK - 1, co, 0, SX);
+        if (!STREAM && (!((FK_KS_SINGLE || FK_KS_EARLY) && !(SK & 1)) || co == 1)) fetch(SK - 1, co, 0, SX);
         if constexpr (SK & 1) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
         // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
         auto batch = [&](auto nb_tag, int j) {
@@ -1299,6 +1365,68 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
 #pragma unroll 1
         for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
         batch(std::integral_constant<int, 1>{}, 0);
+        } else if constexpr (FK_KS_STREAM) {
+        // The operand stream under the inverse transforms: the six products of the NEXT pair of output limbs are taken between the phases of
+        // this pair's transforms (fft_inv2_hooked), each from a register set that is refilled at once with the polynomial W places further on in
+        // the step's stream of 2 * SK * SX operand polynomials.  Two accumulator pairs: the one being transformed, the one being summed.
+        auto batch = [&](auto hn_tag, auto hnn_tag, const int j) {
+            constexpr bool HN = decltype(hn_tag)::value, HNN = decltype(hnn_tag)::value;
+            double acc[2][E];
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int k = 0; k < E; k++) { acc[b][k] = accn[b][k]; accn[b][k] = 0.0; }
+            const int nco = (j >= 3) ? co : 1 - co, nj = (j >= 3) ? j - 2 : SK - 1;
+            const int nnco = (nj >= 3) ? nco : 1 - nco, nnj = (nj >= 3) ? nj - 2 : SK - 1;
+            auto hook = [&](auto stag) {
+                constexpr int q = decltype(stag)::value;
+                if constexpr (HN) {
+                    mac_regs(accn[q / SX], xh[q % SX], w[q % KW]);
+                    pin_regs(accn[q / SX]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (q + KW < NQ) load_ops(w[q % KW], kopnd(nco, nj, q + KW), tid);
+                    else if constexpr (HNN) load_ops(w[q % KW], kopnd(nnco, nnj, q + KW - NQ), tid);
+                }
+            };
+            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
+            fft_inv2_hooked<2>(acc, tw, data, data + LDS_DATA, tid, hook);
+            YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+            if constexpr (SK == 4) { fold_limb4<SK>(od, acc[0], j); fold_limb4<SK>(od, acc[1], j - 1); }
+            else { fold_limb<SK>(od, ec, acc[0], j); fold_limb<SK>(od, ec, acc[1], j - 1); }
+            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
+        };
+        using std::true_type;
+        using std::false_type;
+        if (ci == 0) {
+#pragma unroll 1
+            for (int j = SK - 1; j >= 1; j -= 2) batch(true_type{}, true_type{}, j);
+        } else {
+#pragma unroll 1
+            for (int j = SK - 1; j >= 5; j -= 2) batch(true_type{}, true_type{}, j);
+            batch(true_type{}, false_type{}, 3);
+            batch(false_type{}, false_type{}, 1);
+        }
+        } else if constexpr (FK_KS_SINGLE) {
+        // one output limb at a time, the NEXT limb's operands (the next column's first, at a column's end) requested in front of the
+        // inverse transform: 96 KB in flight under it (a pair of transforms leaves no registers for that)
+#pragma unroll 1
+        for (int j = SK - 1; j >= 0; j--) {
+            double acc[1][E];
+#pragma unroll
+            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+#pragma unroll
+            for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
+            pin_regs(acc[0]);   // the products are taken HERE: sunk below the requests they would wait for them too (vmcnt counts in order)
+            __builtin_amdgcn_sched_barrier(0);
+            if (j >= 1) fetch(j - 1, co, 0, SX);
+            else if (co == 1) fetch(SK - 1, 0, 0, SX);
+            __builtin_amdgcn_sched_barrier(0);
+            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
+            ntt_inv1_loop(acc, tw, data, tid);
+            YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
+            if constexpr (SK == 4) fold_limb4<SK>(od, acc[0], j); else fold_limb<SK>(od, ec, acc[0], j);
+            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
+        }
         } else {
 #pragma unroll 1
         for (int j = SK - 1; j >= 0; j -= 2) {
@@ -1320,6 +1448,16 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
 #pragma unroll
                 for (int r = 0; r < SX; r++) mac_regs(acc[1], xh[r], g[r]);
             }
+#if FK_KS_EARLY
+            // the NEXT pair's first operands (the next column's, at a column's end) requested in front of the inverse transforms: 96 KB in
+            // flight under them.  The products above are pinned in front of the requests: sunk behind them by the compiler (towards their
+            // first use, the transforms) they would wait for the new requests as well — vmcnt counts in order.
+            pin_regs(acc[0]);
+            pin_regs(acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j >= 2) fetch(j - 2, co, 0, SX);
+            else if (co == 1) fetch(SK - 1, 0, 0, SX);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
             if (two) {
@@ -1335,7 +1473,9 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
             // the next limbs' operands: their fetch runs under the first products.  Requested in front of the inverse transforms (one, two or
             // all three polynomials, 0 - 52 spilled registers) the step is 0.7 - 7 % SLOWER: the wait wave 0's stamps show is covered by
             // the SIMD's other wave (profiles/r05_experiments.txt)
+#if !FK_KS_EARLY
             if (j >= 2) fetch(j - 2, co, 0, SX);
+#endif
             YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
         }
         }
@@ -1432,22 +1572,140 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
         if (load_tw) twiddles_commit(twr, tw, tid);
     }
     YSTAMP(1);
+#if FK_EP_STREAM
+    // The operand stream (2 * SA * 2 * SG prepared polynomials of 32 KB: 1.5 MB per product at SG = 4) runs UNDER the transforms:
+    // the products of output limb u + 1 are taken between the phases of limb u's inverse transform and around its fold, each from
+    // a register set that is refilled at once with the polynomial W places further on in the stream (across limbs and columns:
+    // the stream is one sequence).  Two accumulators: the one being transformed, the one being summed.  The first limb's products
+    // have no inverse transform to run under: its first W operands arrive during the first three forward transforms, the next W
+    // during the other three.
+    constexpr int W = FK_EP_WINDOW;
+    constexpr int NQ = 2 * SA;
+    static_assert(W >= 1 && W <= SA, "window");
+    OpRegs w[W];
+    double accn[E];
+    auto opnd = [&](int co_, int j_, int q) { return ggsw + (long)(((2 * (q % SA) + q / SA) * SG + j_) * 2 + co_) * N; };
+    const int co0 = (OUT == 3) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) load_ops(w[i], opnd(co0, SG - 1, i), tid);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     fwd_all<SA>(x0, tw, data, tid);
     YSTAMP(2);
+#if FK_EP_STREAM
+#pragma unroll
+    for (int k = 0; k < E; k++) accn[k] = 0.0;
+#pragma unroll
+    for (int q = 0; q < W; q++) {
+        mac_regs(accn, x0[q], w[q]);
+        pin_regs(accn);
+        __builtin_amdgcn_sched_barrier(0);
+        load_ops(w[q], opnd(co0, SG - 1, q + W), tid);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     if constexpr (IN == 1) digits_of(ac, x1); else if constexpr (IN == 2) digits_of(a1s, x1); else load_limbs(1, x1);
     fwd_all<SA>(x1, tw, data, tid);
     YSTAMP(3);
 
     int it = 0;
+#if FK_EP_STREAM
+#pragma unroll
+    for (int q = W; q < NQ; q++) {
+        mac_regs(accn, q < SA ? x0[q % SA] : x1[q % SA], w[q % W]);
+        pin_regs(accn);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + W < NQ) load_ops(w[q % W], opnd(co0, SG - 1, q + W), tid);
+        else load_ops(w[q % W], opnd(co0, SG - 2, q + W - NQ), tid);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+#if FK_EP_EARLY && !FK_EP_STREAM
+    OpRegs g[SA];   // (lives across the columns: the second column's first operands are requested under the first one's last transform)
+#endif
 #pragma unroll
     for (int cc = 0; cc < 2; cc++) {   // (unrolled: the carried column is written by the second pass only — a rolled loop keeps its old value alive throughout)
         const int co = (OUT == 3) ? 1 - cc : cc;
         double od[E], ec[E];
 #pragma unroll
         for (int k = 0; k < E; k++) { od[k] = 0.0; ec[k] = 0.0; }
-        OpRegs g[SA];
+#if FK_EP_STREAM
+        // one output limb: its inverse transform with the NEXT limb's products between the phases.  HN: there is a next limb in the
+        // stream; HNN: and one behind that (whose first W polynomials are requested here).  Only the last two limbs of a product
+        // differ: they are peeled, so that the steady-state body has no branch.
+        auto unit = [&](auto hn_tag, auto hnn_tag, const int j) {
+            constexpr bool HN = decltype(hn_tag)::value, HNN = decltype(hnn_tag)::value;
+            double acc[1][E];
 #pragma unroll
-        for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co) * N, tid);
+            for (int k = 0; k < E; k++) { acc[0][k] = accn[k]; accn[k] = 0.0; }
+            const int nco = (j > 0) ? co : 1 - co, nj = (j > 0) ? j - 1 : SG - 1;
+            const int nnco = (nj > 0) ? nco : 1 - nco, nnj = (nj > 0) ? nj - 1 : SG - 1;
+            auto step = [&](auto qtag) {
+                constexpr int q = decltype(qtag)::value;
+                if constexpr (HN) {
+                    mac_regs(accn, q < SA ? x0[q % SA] : x1[q % SA], w[q % W]);
+                    pin_regs(accn);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (q + W < NQ) load_ops(w[q % W], opnd(nco, nj, q + W), tid);
+                    else if constexpr (HNN) load_ops(w[q % W], opnd(nnco, nnj, q + W - NQ), tid);
+                }
+            };
+            auto hook = [&](auto stag) {
+                constexpr int sl = decltype(stag)::value;
+                if constexpr (sl == 0) step(std::integral_constant<int, 0>{});
+                if constexpr (sl == 1) { step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); }
+                if constexpr (sl == 2) step(std::integral_constant<int, 3>{});
+            };
+            YSTAMP(8 + (co * SG + (SG - 1 - j)) * 4);
+#if FK_EP_PARK
+            fft_inv1_hooked<2>(acc, tw, data, tid, hook);   // one exchange buffer, fenced by the free counter; buffer 1 holds od
+#else
+            fft_inv1_hooked<0>(acc, tw, data + (it++ & 1) * LDS_DATA, tid, hook);   // double-buffered exchanges: no fence
+#endif
+            YSTAMP(9 + (co * SG + (SG - 1 - j)) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+            step(std::integral_constant<int, 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+#if FK_EP_PARK
+            {   // V of this column lives in this thread's own slots of exchange buffer 1 between the folds (16 registers)
+                double2* odp = reinterpret_cast<double2*>(data + LDS_DATA) + tid;
+                if (j != SG - 1) {
+#pragma unroll
+                    for (int kk = 0; kk < E / 2; kk++) { const double2 v = odp[kk * T]; od[2 * kk] = v.x; od[2 * kk + 1] = v.y; }
+                }
+                if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
+                if (j != 0) {
+#pragma unroll
+                    for (int kk = 0; kk < E / 2; kk++) { double2 v; v.x = od[2 * kk]; v.y = od[2 * kk + 1]; odp[kk * T] = v; }
+                }
+            }
+#else
+            if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            step(std::integral_constant<int, 5>{});
+            __builtin_amdgcn_sched_barrier(0);
+            YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
+        };
+        using std::true_type;
+        using std::false_type;
+        if (cc == 0) {
+#pragma unroll 1
+            for (int j = SG - 1; j >= 0; j--) unit(true_type{}, true_type{}, j);
+        } else {
+#pragma unroll 1
+            for (int j = SG - 1; j >= 2; j--) unit(true_type{}, true_type{}, j);
+            unit(true_type{}, false_type{}, 1);
+            unit(false_type{}, false_type{}, 0);
+        }
+#else
+#if !FK_EP_EARLY
+        OpRegs g[SA];
+#endif
+        if (!FK_EP_EARLY || cc == 0) {
+#pragma unroll
+            for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co) * N, tid);
+        }
 #pragma unroll 1
         for (int j = SG - 1; j >= 0; j--) {
             double acc[1][E];
@@ -1455,6 +1713,39 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
             for (int k = 0; k < E; k++) acc[0][k] = 0.0;
             ep_mac<SA, SG>(acc[0], x0, x1, g, ggsw, j, co, j - 1, tid);
             YSTAMP(8 + (co * SG + (SG - 1 - j)) * 4);
+#if FK_EP_EARLY
+            // the next limb's column_in 0 operands (the next column's first limb's, at a column's end) requested in front of the inverse
+            // transform — behind the products, which are pinned there (see ks_trace_l)
+            pin_regs(acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int fco = (j >= 1) ? co : ((OUT == 3) ? 1 - co : 1 - co), fj = (j >= 1) ? j - 1 : SG - 1;
+                if (j >= 1 || cc == 0) {
+#pragma unroll
+                    for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + fj) * 2 + fco) * N, tid);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#if FK_EP_PARK
+            ntt_inv1_loop(acc, tw, data, tid);   // one exchange buffer, fenced by the free counter; buffer 1 holds V between the folds
+            {
+                double2* odp = reinterpret_cast<double2*>(data + LDS_DATA) + tid;
+                if (j != SG - 1) {
+#pragma unroll
+                    for (int kk = 0; kk < E / 2; kk++) { const double2 v = odp[kk * T]; od[2 * kk] = v.x; od[2 * kk + 1] = v.y; }
+                }
+                if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
+                if (j != 0) {
+#pragma unroll
+                    for (int kk = 0; kk < E / 2; kk++) { double2 v; v.x = od[2 * kk]; v.y = od[2 * kk + 1]; odp[kk * T] = v; }
+                }
+            }
+#else
+            ntt_inv<1, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);   // double-buffered exchanges: no fence
+            if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
+#endif
+            YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
+#else
             ntt_inv<1, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);   // double-buffered exchanges: no fence
             YSTAMP(9 + (co * SG + (SG - 1 - j)) * 4);
             const bool more = j >= 1;
@@ -1466,7 +1757,9 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
             __builtin_amdgcn_sched_barrier(0);
             fetch1(2);
             YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
+#endif
         }
+#endif
 #pragma unroll
         for (int k = 0; k < E; k++) {
             double a_ = window51(od[k]);

@@ -103,6 +103,105 @@ __global__ __launch_bounds__(T, 2) void k_time_occ2(const double* tw_g, double* 
     sink[blockIdx.x * T + threadIdx.x] = s;
 }
 
+// Does the operand stream overlap a transform?  Per repetition: P operand polynomials (32 KB each, from a 768 KB key every workgroup
+// shares: the XCD's L2) are REQUESTED, an inverse pair runs, the operands are consumed by multiply-accumulates.
+//   WHAT 0: loads + transforms + MACs   1: loads + MACs (no transform)   2: transforms + MACs on stale registers (no loads)
+template <int P, int WHAT>
+__global__ __launch_bounds__(T, T / 256) void k_stream(const double* tw_g, double* sink, int reps, const double* key) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = vt((int)threadIdx.x);
+    load_twiddles(tw, tw_g, tid);
+    double x[2][E], acc[2][E];
+    for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) { x[b][k] = (double)((tid * 8 + k + b) & 1023); acc[b][k] = 0.0; }
+    double2 g[P][E / 2];
+    for (int q = 0; q < P; q++) for (int kk = 0; kk < E / 2; kk++) { g[q][kk].x = 1e-3; g[q][kk].y = 2e-3; }
+    int poly = 0;
+    for (int r = 0; r < reps; r++) {
+        if (WHAT != 2) {
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                const double2* gp = reinterpret_cast<const double2*>(key + (long)poly * N);
+#pragma unroll
+                for (int kk = 0; kk < E / 2; kk++) g[q][kk] = gp[kk * T + tid];
+                poly = (poly + 1) % 24;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (WHAT != 1) ntt_inv2_loop(x, tw, data, data + LDS_DATA, tid);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < P; q++)
+#pragma unroll
+            for (int kk = 0; kk < E / 2; kk++) {
+                acc[q & 1][2 * kk] = __builtin_fma(x[q & 1][2 * kk], g[q][kk].x, acc[q & 1][2 * kk]);
+                acc[q & 1][2 * kk] = __builtin_fma(-x[q & 1][2 * kk + 1], g[q][kk].y, acc[q & 1][2 * kk]);
+                acc[q & 1][2 * kk + 1] = __builtin_fma(x[q & 1][2 * kk], g[q][kk].y, acc[q & 1][2 * kk + 1]);
+                acc[q & 1][2 * kk + 1] = __builtin_fma(x[q & 1][2 * kk + 1], g[q][kk].x, acc[q & 1][2 * kk + 1]);
+            }
+        for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) x[b][k] = acc[b][k] * 1e-6;
+    }
+    double s_ = 0;
+    for (int b = 0; b < 2; b++) for (int k = 0; k < E; k++) s_ += x[b][k];
+    sink[blockIdx.x * T + threadIdx.x] = s_;
+}
+
+// The chain kernels' streamed form: ONE inverse transform per repetition with the multiply-accumulates of six operand polynomials between
+// its phases (fft_inv1_hooked), each from a register set refilled at once with the polynomial W places further on.  W = in-flight window.
+template <int W, bool LOADS>
+__global__ __launch_bounds__(T, T / 256) void k_rolling(const double* tw_g, double* sink, int reps, const double* key) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* tw = lds;
+    double* data = lds + LDS_TW;
+    const int tid = vt((int)threadIdx.x);
+    load_twiddles(tw, tw_g, tid);
+    double x[1][E], xs[E], accn[E];
+    for (int k = 0; k < E; k++) { x[0][k] = (double)((tid * 8 + k) & 1023); xs[k] = x[0][k] * 1e-3; accn[k] = 0.0; }
+    double2 w[W][E / 2];
+    int poly = 0;
+    auto request = [&](int slot) {
+        if (LOADS) {
+            const double2* gp = reinterpret_cast<const double2*>(key + (long)poly * N);
+#pragma unroll
+            for (int kk = 0; kk < E / 2; kk++) w[slot][kk] = gp[kk * T + tid];
+        }
+        poly = (poly + 1) % 24;
+    };
+    for (int i = 0; i < W; i++) { for (int kk = 0; kk < E / 2; kk++) { w[i][kk].x = 1e-3; w[i][kk].y = 2e-3; } request(i); }
+    for (int r = 0; r < reps; r++) {
+        auto step = [&](auto qtag) {
+            constexpr int q = decltype(qtag)::value;
+            constexpr int sl = q % W;
+#pragma unroll
+            for (int kk = 0; kk < E / 2; kk++) {
+                accn[2 * kk] = __builtin_fma(xs[2 * kk], w[sl][kk].x, accn[2 * kk]);
+                accn[2 * kk] = __builtin_fma(-xs[2 * kk + 1], w[sl][kk].y, accn[2 * kk]);
+                accn[2 * kk + 1] = __builtin_fma(xs[2 * kk], w[sl][kk].y, accn[2 * kk + 1]);
+                accn[2 * kk + 1] = __builtin_fma(xs[2 * kk + 1], w[sl][kk].x, accn[2 * kk + 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < E; k++) asm volatile("" : "+v"(accn[k]));
+            __builtin_amdgcn_sched_barrier(0);
+            request(sl);
+        };
+        auto hook = [&](auto stag) {
+            constexpr int s_ = decltype(stag)::value;
+            if constexpr (s_ == 0) step(std::integral_constant<int, 0>{});
+            if constexpr (s_ == 1) { step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); }
+            if constexpr (s_ == 2) step(std::integral_constant<int, 3>{});
+        };
+        fft_inv1_hooked<2>(x, tw, data, tid, hook);
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        for (int k = 0; k < E; k++) { x[0][k] = accn[k] * 1e-6 + x[0][k] * 1e-3; accn[k] = 0.0; }
+    }
+    double s_ = 0;
+    for (int k = 0; k < E; k++) s_ += x[0][k];
+    for (int i = 0; i < W; i++) for (int kk = 0; kk < E / 2; kk++) s_ += w[i][kk].x;
+    sink[blockIdx.x * T + threadIdx.x] = s_;
+}
+
 static void exact_negacyclic(const int* a, const int* g, long long* c) {
     std::vector<__int128> t(2 * N, 0);
     for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) t[i + j] += (__int128)a[i] * g[j];
@@ -166,6 +265,34 @@ int main() {
     timeit(k_time<12>, "inverse, 2 half a phase apart", tw, sink, 256, 2);
     timeit(k_time<13>, "inverse, 3 half a phase apart", tw, sink, 256, 3);
     timeit(k_time<22>, "inverse, 2, fenced by the free counter", tw, sink, 256, 2);
+    {
+        double* key;
+        hipMalloc(&key, 24 * N * sizeof(double));
+        hipMemset(key, 0, 24 * N * sizeof(double));
+        auto run = [&](auto kern, const char* name) {
+            const int reps = 2000;
+            hipLaunchKernelGGL(kern, dim3(256), dim3(T), LDS_BYTES, 0, tw, sink, 10, key);
+            hipDeviceSynchronize();
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kern, dim3(256), dim3(T), LDS_BYTES, 0, tw, sink, reps, key);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-78s %7.3f us per repetition\n", name, ms * 1e3 / reps);
+        };
+        run(k_stream<3, 2>, "inverse pair + 3 MACs, no loads");
+        run(k_stream<3, 1>, "3 operand polynomials (96 KB per CU) + 3 MACs, no transform");
+        run(k_stream<3, 0>, "3 operand polynomials requested in front of the inverse pair, + 3 MACs");
+        run(k_stream<6, 2>, "inverse pair + 6 MACs, no loads");
+        run(k_stream<6, 1>, "6 operand polynomials (192 KB per CU) + 6 MACs, no transform");
+        run(k_stream<6, 0>, "6 operand polynomials requested in front of the inverse pair, + 6 MACs");
+        run(k_rolling<2, false>, "one inverse transform + 6 MACs between its phases, no loads");
+        run(k_rolling<1, true>, "  ... 6 operand polynomials (192 KB) through a window of 1");
+        run(k_rolling<2, true>, "  ... through a window of 2");
+        run(k_rolling<3, true>, "  ... through a window of 3");
+        run(k_rolling<4, true>, "  ... through a window of 4");
+        run(k_rolling<6, true>, "  ... through a window of 6");
+    }
     const size_t lds1 = (size_t)(LDS_TW + LDS_DATA) * sizeof(double);   // 69 632 B: two workgroups fit a CU's 160 KB
     timeit(k_time_occ2<1>, "forward, 1, ONE workgroup per CU (same kernel)", tw, sink, 256, 1, lds1);
     timeit(k_time_occ2<1>, "forward, 1, TWO workgroups per CU", tw, sink, 512, 2, lds1);
