@@ -360,8 +360,8 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
 }
 
 // ---- ONE inverse transform with work of the caller's between its phases -------------------------------------------------------------
-// hook(std::integral_constant<int, s>) is called at three points where the wave would otherwise wait for LDS: s = 0 behind the
-// issue of exchange 1, s = 1 behind the stores of exchange 0 (in front of the rendezvous), s = 2 behind the issue of its loads.
+// hook(std::integral_constant<int, s>) is called at four points: s = 0 behind the issue of exchange 1, s = 1 behind the stores of
+// exchange 0 (in front of the rendezvous), s = 2 behind the issue of its loads, s = 3 behind the last pass (in front of the rounding).
 // The callers stream prepared operands through there (global loads requested, multiply-accumulates of the NEXT output limb
 // taken): the operand stream of a chain step — 0.75 to 1.5 MB per step through the CU's ~57 B/clk load path — then runs under the
 // transforms instead of beside them (tools/fft_bench.hip, k_stream: a transform pair with 192 KB requested in front of it takes
@@ -400,8 +400,11 @@ __device__ __forceinline__ void fft_inv1_hooked(double (&x)[1][E], const double*
     hook(std::integral_constant<int, 2>{});
     __builtin_amdgcn_sched_barrier(0);
     i_pass3(y, t0);
+    if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));   // (behind the last cross-wave load, whose data pass 3 has consumed)
+    __builtin_amdgcn_sched_barrier(0);
+    hook(std::integral_constant<int, 3>{});
+    __builtin_amdgcn_sched_barrier(0);
     nat_out<ROUND>(y, x[0]);
-    if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
 }
 
 // ---- TWO inverse transforms half a phase apart with work of the caller's between their phases (six places) ------------------------------

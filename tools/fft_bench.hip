@@ -186,10 +186,7 @@ __global__ __launch_bounds__(T, T / 256) void k_rolling(const double* tw_g, doub
             request(sl);
         };
         auto hook = [&](auto stag) {
-            constexpr int s_ = decltype(stag)::value;
-            if constexpr (s_ == 0) step(std::integral_constant<int, 0>{});
-            if constexpr (s_ == 1) { step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); }
-            if constexpr (s_ == 2) step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, decltype(stag)::value>{});
         };
         fft_inv1_hooked<2>(x, tw, data, tid, hook);
         step(std::integral_constant<int, 4>{});
