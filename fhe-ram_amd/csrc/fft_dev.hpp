@@ -366,9 +366,6 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
 // taken): the operand stream of a chain step — 0.75 to 1.5 MB per step through the CU's ~57 B/clk load path — then runs under the
 // transforms instead of beside them (tools/fft_bench.hip, k_stream: a transform pair with 192 KB requested in front of it takes
 // 3.19 us against 3.04 without the loads and 1.60 for the loads alone).
-#ifndef FK_HOOK_TW_LATE
-#define FK_HOOK_TW_LATE 1
-#endif
 template <int FENCE, bool ROUND = true, class Hook>
 __device__ __forceinline__ void fft_inv1_hooked(double (&x)[1][E], const double* tw_, double* d0, int tid, Hook&& hook) {
     const d2* tw = reinterpret_cast<const d2*>(tw_);
@@ -382,20 +379,18 @@ __device__ __forceinline__ void fft_inv1_hooked(double (&x)[1][E], const double*
     if constexpr (FENCE == 2) sb_wait_free(sb_addr(tw_));
     i_pass4(y, t2);
     x1b_w(y, buf, xa); wave_lds_fence(); x1a_r(y, buf, xa);
-    if constexpr (!FK_HOOK_TW_LATE) tw_p1(t1, tw, xa);
     __builtin_amdgcn_sched_barrier(0);
     hook(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (FK_HOOK_TW_LATE) tw_p1(t1, tw, xa);   // (behind the hook: 20 registers fewer are live across it)
+    tw_p1(t1, tw, xa);   // (behind the hook: 20 registers fewer are live across it)
     i_pass4(y, t1);
     x0b_w(y, buf, xa);
-    if constexpr (!FK_HOOK_TW_LATE) tw_p0(t0, tw, xa);
     __builtin_amdgcn_sched_barrier(0);
     hook(std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
     x0a_r(y, buf, xa);
-    if constexpr (FK_HOOK_TW_LATE) tw_p0(t0, tw, xa);
+    tw_p0(t0, tw, xa);
     __builtin_amdgcn_sched_barrier(0);
     hook(std::integral_constant<int, 2>{});
     __builtin_amdgcn_sched_barrier(0);

@@ -324,29 +324,11 @@ constexpr int BF = FK_BF, BI = FK_BI;
 static_assert(BF <= BMAX && BI <= BMAX, "LDS holds BMAX exchange buffers");
 
 // forward transform of S polynomials, BF at a time
-#ifndef FK_KS_STREAM
-#define FK_KS_STREAM 1    // ks_trace_l (even limb counts): the operand stream under the pairs of inverse transforms (fft_inv2_hooked)
-#endif
 #ifndef FK_KS_WINDOW
-#define FK_KS_WINDOW 2
-#endif
-#ifndef FK_KS_EARLY
-#define FK_KS_EARLY 0     // ks_trace_l (even limb counts): the next pair's first operands requested in front of the inverse transforms
-#endif
-#ifndef FK_KS_SINGLE
-#define FK_KS_SINGLE 0    // ks_trace_l (even limb counts): single inverse transforms with the next limb's operands in flight under them
-#endif
-#ifndef FK_EP_STREAM
-#define FK_EP_STREAM 1    // ep_step_r: the operand stream runs under the inverse transforms (fft_inv1_hooked)
-#endif
-#ifndef FK_EP_EARLY
-#define FK_EP_EARLY 0     // ep_step_r: the next limb's first three operands requested in front of the inverse transform
-#endif
-#ifndef FK_EP_PARK
-#define FK_EP_PARK 1      // ... and the column's running sum V is parked in LDS between the folds
+#define FK_KS_WINDOW 2    // ks_trace_l: operand polynomials in flight under the transforms (16 registers each; 3: 69 spilled registers, slower)
 #endif
 #ifndef FK_EP_WINDOW
-#define FK_EP_WINDOW 2    // operand polynomials in flight (16 registers each)
+#define FK_EP_WINDOW 2    // ep_step_r: the same (3: 75 spilled registers, slower)
 #endif
 #ifndef FK_FWD_SKEW
 #define FK_FWD_SKEW 1   // ks_trace_l: the three forward transforms half a phase apart (ntt_fwd3_skew): trace step 35.8 -> 35.6 us, step 2.198 -> 2.18 ms; the same in the products: +1 % per product, not used there
@@ -1188,6 +1170,8 @@ __device__ __forceinline__ void fold_limb4(double (&od)[E], const double (&acc)[
 // inverse transforms.  No global loads or stores between the steps (round 3's register hand-over kept the global round trip
 // of the gathers' staging; here it is gone), no store drain at a step's end, and one workgroup barrier fewer per step.
 //   IN_Y  : the input comes that way (else: an int32 GLWE, first step)    OUT_Y : the output leaves that way (else int32, last step)
+// Round 5: for an even limb count the 2 * SK * SX operand polynomials of a step (768 KB at SK = 4) stream under the pairs of inverse
+// transforms (fft_inv2_hooked): the products of the next pair of output limbs are taken between the phases of this pair's transforms.
 // ---------------------------------------------------------------------------------------
 //   OUT2: (k_write_chain) the last trace step of write_mid_step hands normalize(ct_hi - trace(ct_hi) + trace(ct_lo X^-row)) (ram.rs:617,625-626)
 //   to write_last_step's products: ka.b = the row (ct_hi), ka.out = trace(ct_hi); the result leaves as A (not Y), the mask column in
@@ -1265,7 +1249,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         for (int r = 0; r < SX; r++)
             if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
     };
-    constexpr bool STREAM = FK_KS_STREAM && !(SK & 1);
+    constexpr bool STREAM = !(SK & 1);   // (an odd limb count — the README block's keys — keeps the unstreamed pairs + one)
     constexpr int KW = FK_KS_WINDOW, NQ = 2 * SX;
     [[maybe_unused]] OpRegs w[STREAM ? KW : 1];
     [[maybe_unused]] double accn[2][E];
@@ -1325,7 +1309,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         }
 #pragma unroll
         for (int k = 0; k < E; k++) ec[k] = 0.0;
-        if (!STREAM && (!((FK_KS_SINGLE || FK_KS_EARLY) && !(SK & 1)) || co == 1)) fetch(SK - 1, co, 0, SX);
+        if (!STREAM) fetch(SK - 1, co, 0, SX);
         if constexpr (SK & 1) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
         // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
         auto batch = [&](auto nb_tag, int j) {
@@ -1365,7 +1349,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
 #pragma unroll 1
         for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
         batch(std::integral_constant<int, 1>{}, 0);
-        } else if constexpr (FK_KS_STREAM) {
+        } else {
         // The operand stream under the inverse transforms: the six products of the NEXT pair of output limbs are taken between the phases of
         // this pair's transforms (fft_inv2_hooked), each from a register set that is refilled at once with the polynomial W places further on in
         // the step's stream of 2 * SK * SX operand polynomials.  Two accumulator pairs: the one being transformed, the one being summed.
@@ -1406,78 +1390,6 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
             batch(true_type{}, false_type{}, 3);
             batch(false_type{}, false_type{}, 1);
         }
-        } else if constexpr (FK_KS_SINGLE) {
-        // one output limb at a time, the NEXT limb's operands (the next column's first, at a column's end) requested in front of the
-        // inverse transform: 96 KB in flight under it (a pair of transforms leaves no registers for that)
-#pragma unroll 1
-        for (int j = SK - 1; j >= 0; j--) {
-            double acc[1][E];
-#pragma unroll
-            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
-#pragma unroll
-            for (int r = 0; r < SX; r++) mac_regs(acc[0], xh[r], g[r]);
-            pin_regs(acc[0]);   // the products are taken HERE: sunk below the requests they would wait for them too (vmcnt counts in order)
-            __builtin_amdgcn_sched_barrier(0);
-            if (j >= 1) fetch(j - 1, co, 0, SX);
-            else if (co == 1) fetch(SK - 1, 0, 0, SX);
-            __builtin_amdgcn_sched_barrier(0);
-            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
-            ntt_inv1_loop(acc, tw, data, tid);
-            YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-            if constexpr (SK == 4) fold_limb4<SK>(od, acc[0], j); else fold_limb<SK>(od, ec, acc[0], j);
-            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
-        }
-        } else {
-#pragma unroll 1
-        for (int j = SK - 1; j >= 0; j -= 2) {
-            const bool two = j >= 1;    // (always, for an even limb count; written as a condition: the register allocator's result depends on the shape of this loop)
-            double acc[2][E];
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
-            // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
-#pragma unroll
-            for (int r = 0; r < SX; r++) {
-                mac_regs(acc[0], xh[r], g[r]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (two) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (two) {
-#pragma unroll
-                for (int r = 0; r < SX; r++) mac_regs(acc[1], xh[r], g[r]);
-            }
-#if FK_KS_EARLY
-            // the NEXT pair's first operands (the next column's, at a column's end) requested in front of the inverse transforms: 96 KB in
-            // flight under them.  The products above are pinned in front of the requests: sunk behind them by the compiler (towards their
-            // first use, the transforms) they would wait for the new requests as well — vmcnt counts in order.
-            pin_regs(acc[0]);
-            pin_regs(acc[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j >= 2) fetch(j - 2, co, 0, SX);
-            else if (co == 1) fetch(SK - 1, 0, 0, SX);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
-            if (two) {
-                ntt_inv2_loop(acc, tw, data, data + LDS_DATA, tid);   // (fenced against the previous pair's cross-wave readers by the free counter, not by a barrier)
-                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                if constexpr (SK == 4) { fold_limb4<SK>(od, acc[0], j); fold_limb4<SK>(od, acc[1], j - 1); }
-                else { fold_limb<SK>(od, ec, acc[0], j); fold_limb<SK>(od, ec, acc[1], j - 1); }
-            } else {
-                ntt_inv1_loop(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, data, tid);
-                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                if constexpr (SK == 4) fold_limb4<SK>(od, acc[0], j); else fold_limb<SK>(od, ec, acc[0], j);
-            }
-            // the next limbs' operands: their fetch runs under the first products.  Requested in front of the inverse transforms (one, two or
-            // all three polynomials, 0 - 52 spilled registers) the step is 0.7 - 7 % SLOWER: the wait wave 0's stamps show is covered by
-            // the SIMD's other wave (profiles/r05_experiments.txt)
-#if !FK_KS_EARLY
-            if (j >= 2) fetch(j - 2, co, 0, SX);
-#endif
-            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
-        }
         }
 #pragma unroll
         for (int k = 0; k < E; k++) {
@@ -1516,7 +1428,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
 // travels as A = the integer whose balanced base-2^17 digits are the three output limbs (closed-form normalisation, see
 // ks_trace_z: one accumulator per coefficient, no carry chain), column 1 in registers (ac), column 0 — finished first — in
 // this wave's own region of the third exchange buffer, which the inverse transforms leave alone.  The consumer takes its digits
-// with take_digit.  Same streaming structure as ep_run (operands of the next limb requested around the normalisation step).
+// with take_digit.  The operand stream runs under the transforms (round 5: see the comment at the first request below).
 //   IN_R : the input comes that way (else an int32 GLWE: first product)     OUT_R : the output leaves that way (else int32: last)
 // ---------------------------------------------------------------------------------------
 //   IN : 0 an int32 GLWE (first product), 1 from the previous product (column 0 parked in LDS, column 1 in ac), 2 from a trace step
@@ -1572,7 +1484,6 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
         if (load_tw) twiddles_commit(twr, tw, tid);
     }
     YSTAMP(1);
-#if FK_EP_STREAM
     // The operand stream (2 * SA * 2 * SG prepared polynomials of 32 KB: 1.5 MB per product at SG = 4) runs UNDER the transforms:
     // the products of output limb u + 1 are taken between the phases of limb u's inverse transform and around its fold, each from
     // a register set that is refilled at once with the polynomial W places further on in the stream (across limbs and columns:
@@ -1589,10 +1500,8 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
 #pragma unroll
     for (int i = 0; i < W; i++) load_ops(w[i], opnd(co0, SG - 1, i), tid);
     __builtin_amdgcn_sched_barrier(0);
-#endif
     fwd_all<SA>(x0, tw, data, tid);
     YSTAMP(2);
-#if FK_EP_STREAM
 #pragma unroll
     for (int k = 0; k < E; k++) accn[k] = 0.0;
 #pragma unroll
@@ -1603,13 +1512,9 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
         load_ops(w[q], opnd(co0, SG - 1, q + W), tid);
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
     if constexpr (IN == 1) digits_of(ac, x1); else if constexpr (IN == 2) digits_of(a1s, x1); else load_limbs(1, x1);
     fwd_all<SA>(x1, tw, data, tid);
     YSTAMP(3);
-
-    int it = 0;
-#if FK_EP_STREAM
 #pragma unroll
     for (int q = W; q < NQ; q++) {
         mac_regs(accn, q < SA ? x0[q % SA] : x1[q % SA], w[q % W]);
@@ -1619,17 +1524,12 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
         else load_ops(w[q % W], opnd(co0, SG - 2, q + W - NQ), tid);
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
-#if FK_EP_EARLY && !FK_EP_STREAM
-    OpRegs g[SA];   // (lives across the columns: the second column's first operands are requested under the first one's last transform)
-#endif
 #pragma unroll
     for (int cc = 0; cc < 2; cc++) {   // (unrolled: the carried column is written by the second pass only — a rolled loop keeps its old value alive throughout)
         const int co = (OUT == 3) ? 1 - cc : cc;
         double od[E], ec[E];
 #pragma unroll
         for (int k = 0; k < E; k++) { od[k] = 0.0; ec[k] = 0.0; }
-#if FK_EP_STREAM
         // one output limb: its inverse transform with the NEXT limb's products between the phases.  HN: there is a next limb in the
         // stream; HNN: and one behind that (whose first W polynomials are requested here).  Only the last two limbs of a product
         // differ: they are peeled, so that the steady-state body has no branch.
@@ -1655,17 +1555,12 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
                 step(std::integral_constant<int, sl>{});   // one product per place: evenly spaced requests
             };
             YSTAMP(8 + (co * SG + (SG - 1 - j)) * 4);
-#if FK_EP_PARK
-            fft_inv1_hooked<2>(acc, tw, data, tid, hook);   // one exchange buffer, fenced by the free counter; buffer 1 holds od
-#else
-            fft_inv1_hooked<0>(acc, tw, data + (it++ & 1) * LDS_DATA, tid, hook);   // double-buffered exchanges: no fence
-#endif
+            fft_inv1_hooked<2>(acc, tw, data, tid, hook);   // one exchange buffer, fenced by the free counter; buffer 1 holds V (below)
             YSTAMP(9 + (co * SG + (SG - 1 - j)) * 4);
             __builtin_amdgcn_sched_barrier(0);
             step(std::integral_constant<int, 4>{});
             __builtin_amdgcn_sched_barrier(0);
-#if FK_EP_PARK
-            {   // V of this column lives in this thread's own slots of exchange buffer 1 between the folds (16 registers)
+            {   // V of this column lives in this thread's own slots of exchange buffer 1 between the folds (16 registers fewer across the transform)
                 double2* odp = reinterpret_cast<double2*>(data + LDS_DATA) + tid;
                 if (j != SG - 1) {
 #pragma unroll
@@ -1677,9 +1572,6 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
                     for (int kk = 0; kk < E / 2; kk++) { double2 v; v.x = od[2 * kk]; v.y = od[2 * kk + 1]; odp[kk * T] = v; }
                 }
             }
-#else
-            if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             step(std::integral_constant<int, 5>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -1696,68 +1588,6 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
             unit(true_type{}, false_type{}, 1);
             unit(false_type{}, false_type{}, 0);
         }
-#else
-#if !FK_EP_EARLY
-        OpRegs g[SA];
-#endif
-        if (!FK_EP_EARLY || cc == 0) {
-#pragma unroll
-            for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (SG - 1)) * 2 + co) * N, tid);
-        }
-#pragma unroll 1
-        for (int j = SG - 1; j >= 0; j--) {
-            double acc[1][E];
-#pragma unroll
-            for (int k = 0; k < E; k++) acc[0][k] = 0.0;
-            ep_mac<SA, SG>(acc[0], x0, x1, g, ggsw, j, co, j - 1, tid);
-            YSTAMP(8 + (co * SG + (SG - 1 - j)) * 4);
-#if FK_EP_EARLY
-            // the next limb's column_in 0 operands (the next column's first limb's, at a column's end) requested in front of the inverse
-            // transform — behind the products, which are pinned there (see ks_trace_l)
-            pin_regs(acc[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const int fco = (j >= 1) ? co : ((OUT == 3) ? 1 - co : 1 - co), fj = (j >= 1) ? j - 1 : SG - 1;
-                if (j >= 1 || cc == 0) {
-#pragma unroll
-                    for (int r = 0; r < SA; r++) load_ops(g[r], ggsw + (long)(((2 * r) * SG + fj) * 2 + fco) * N, tid);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#if FK_EP_PARK
-            ntt_inv1_loop(acc, tw, data, tid);   // one exchange buffer, fenced by the free counter; buffer 1 holds V between the folds
-            {
-                double2* odp = reinterpret_cast<double2*>(data + LDS_DATA) + tid;
-                if (j != SG - 1) {
-#pragma unroll
-                    for (int kk = 0; kk < E / 2; kk++) { const double2 v = odp[kk * T]; od[2 * kk] = v.x; od[2 * kk + 1] = v.y; }
-                }
-                if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
-                if (j != 0) {
-#pragma unroll
-                    for (int kk = 0; kk < E / 2; kk++) { double2 v; v.x = od[2 * kk]; v.y = od[2 * kk + 1]; odp[kk * T] = v; }
-                }
-            }
-#else
-            ntt_inv<1, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);   // double-buffered exchanges: no fence
-            if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
-#endif
-            YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
-#else
-            ntt_inv<1, false>(acc, tw, data + (it++ & 1) * LDS_DATA, tid);   // double-buffered exchanges: no fence
-            YSTAMP(9 + (co * SG + (SG - 1 - j)) * 4);
-            const bool more = j >= 1;
-            auto fetch1 = [&](int r) { if (more) load_ops(g[r], ggsw + (long)(((2 * r) * SG + (j - 1)) * 2 + co) * N, tid); };
-            fetch1(0);
-            fetch1(1);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (SG == 4) fold_limb4<SG>(od, acc[0], j); else fold_limb<SG>(od, ec, acc[0], j);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch1(2);
-            YSTAMP(10 + (co * SG + (SG - 1 - j)) * 4);
-#endif
-        }
-#endif
 #pragma unroll
         for (int k = 0; k < E; k++) {
             double a_ = window51(od[k]);
