@@ -714,7 +714,8 @@ def main():
                 "MAC: 2.47x the FP64 instructions per key-switch, 2.66x per product) — the same launch at round 4's count is "
                 "frac_at_round4_instruction_count, for comparison with the r04 profiles only.  What now shares the step with the FP64 "
                 "pipe: the swap rounds and address arithmetic of the transforms (VALU, not FP64), two 32 KB LDS exchanges per transform, and "
-                "the prepared operands streamed from L2 (32 KB per polynomial MAC at the CU's 64 B/clk): see `pipes`.")
+                "the prepared operands streamed from the XCD's L2 under the inverse transforms (32 KB per polynomial MAC; at 2^18 the product runs at "
+                "~60 % of the L2's share per CU): see `pipes`.")
         if table:
             dom = dict(table[0])
             ratio = None
@@ -746,7 +747,13 @@ def main():
                             "fp64_busy_frac": dom["frac"],
                             "lds_bytes": lds_bytes, "lds_GBs_per_cu": lds_bytes / t_launch / 1e9, "lds_peak_GBs_per_cu": "~85 B/clk stores, 256 B/clk loads (MI355X_MICROARCH.md LDS table): 186 / 560",
                             "operand_bytes_from_l2": opnd_bytes, "operand_GBs_per_cu": opnd_bytes / t_launch / 1e9, "operand_peak_GBs_per_cu": 64 * 2.19,
-                            "operand_frac": opnd_bytes / t_launch / 1e9 / (64 * 2.19)}
+                            "operand_frac": opnd_bytes / t_launch / 1e9 / (64 * 2.19),
+                            "operand_l2_share_GBs_per_cu": 70.0,
+                            "operand_frac_of_l2_share": opnd_bytes / t_launch / 1e9 / 70.0,
+                            "operand_note": "every workgroup of a launch streams the SAME key / GGSW from its XCD's L2: with all 32 CUs of an XCD streaming shared rows the L2 gives each "
+                                            "66-73 GB/s (MI355X_MICROARCH.md, 'Indexed rows'), not the 64 B/clk of the CU's own load path.  The stream runs under the inverse transforms "
+                                            "(fft_inv1_hooked / fft_inv2_hooked); what it still costs is measured by building with -DFK_NO_OPERANDS / -DFK_HALF_OPERANDS "
+                                            "(profiles/r05_experiments.txt): 4.1 us of a 23.1 us trace step, 6.3 us of a 34.1 us product; with half the bytes 1.6 and 1.7"}
             out["roofline"] = dom
             out["roofline_by_kernel"] = {"what": "every launch class of the step (disjoint), largest GPU time first; share_of_gpu_time is of the summed kernel time of the instrumented pass",
                                          "kernels": [{k: v for k, v in e.items()} for e in table if e["share_of_gpu_time"] >= 0.05],

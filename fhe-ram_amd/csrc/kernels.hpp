@@ -254,6 +254,9 @@ __device__ __forceinline__ void load_ops(OpRegs& o, const double* __restrict__ g
     asm("" : "+v"(off));   // opaque per call: the zero extension of the offset must stay next to the loads (not hoisted out of the limb loop) for the scalar-base form to be selected
 #pragma unroll
     for (int kk = 0; kk < E / 2; kk++) {
+#ifdef FK_HALF_OPERANDS   // measurement only (wrong results): half the operand bytes
+        if (kk >= E / 4) { asm volatile("" : "=v"(o.v[kk].x), "=v"(o.v[kk].y)); continue; }
+#endif
         gbytes base = (gbytes)uniform_u64((unsigned long long)g + (unsigned long long)kk * T * 16);
         asm("" : "+s"(base));
         const d2v w = *(gwords)(base + off);
@@ -271,6 +274,15 @@ __device__ __forceinline__ void load_ops(OpRegs& o, const double* __restrict__ g
 __device__ __forceinline__ void pin_regs(double (&x)[E]) {
 #pragma unroll
     for (int k = 0; k < E; k++) asm volatile("" : "+v"(x[k]));
+}
+// (the first products of a step, which have no transform to run under: measured apart with -DFK_NO_PROLOGUE_OPS)
+__device__ __forceinline__ void load_ops_p(OpRegs& o, const double* __restrict__ g, int tid) {
+#ifdef FK_NO_PROLOGUE_OPS
+#pragma unroll
+    for (int kk = 0; kk < E / 2; kk++) asm volatile("" : "=v"(o.v[kk].x), "=v"(o.v[kk].y));
+#else
+    load_ops(o, g, tid);
+#endif
 }
 __device__ __forceinline__ void mac_regs(double (&acc)[E], const double (&x)[E], const OpRegs& o) {
 #pragma unroll
@@ -1257,7 +1269,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
     [[maybe_unused]] auto kopnd = [&](int co_, int j_, int q) { return ka.key + (long)(((q % SX) * SK + (j_ - q / SX)) * 2 + co_) * N; };
     if constexpr (STREAM) {
 #pragma unroll
-        for (int i = 0; i < KW; i++) load_ops(w[i], kopnd(1, SK - 1, i), tid);
+        for (int i = 0; i < KW; i++) load_ops_p(w[i], kopnd(1, SK - 1, i), tid);
         __builtin_amdgcn_sched_barrier(0);
     }
     YSTAMP(2);
@@ -1281,7 +1293,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
             mac_regs(accn[q / SX], xh[q % SX], w[q % KW]);
             pin_regs(accn[q / SX]);
             __builtin_amdgcn_sched_barrier(0);
-            if (q + KW < NQ) load_ops(w[q % KW], kopnd(1, SK - 1, q + KW), tid);
+            if (q + KW < NQ) load_ops_p(w[q % KW], kopnd(1, SK - 1, q + KW), tid);
             else load_ops(w[q % KW], kopnd(SK >= 4 ? 1 : 0, SK >= 4 ? SK - 3 : SK - 1, q + KW - NQ), tid);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1498,7 +1510,7 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
     auto opnd = [&](int co_, int j_, int q) { return ggsw + (long)(((2 * (q % SA) + q / SA) * SG + j_) * 2 + co_) * N; };
     const int co0 = (OUT == 3) ? 1 : 0;
 #pragma unroll
-    for (int i = 0; i < W; i++) load_ops(w[i], opnd(co0, SG - 1, i), tid);
+    for (int i = 0; i < W; i++) load_ops_p(w[i], opnd(co0, SG - 1, i), tid);
     __builtin_amdgcn_sched_barrier(0);
     fwd_all<SA>(x0, tw, data, tid);
     YSTAMP(2);
@@ -1509,7 +1521,7 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
         mac_regs(accn, x0[q], w[q]);
         pin_regs(accn);
         __builtin_amdgcn_sched_barrier(0);
-        load_ops(w[q], opnd(co0, SG - 1, q + W), tid);
+        load_ops_p(w[q], opnd(co0, SG - 1, q + W), tid);
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (IN == 1) digits_of(ac, x1); else if constexpr (IN == 2) digits_of(a1s, x1); else load_limbs(1, x1);
@@ -1520,7 +1532,7 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
         mac_regs(accn, q < SA ? x0[q % SA] : x1[q % SA], w[q % W]);
         pin_regs(accn);
         __builtin_amdgcn_sched_barrier(0);
-        if (q + W < NQ) load_ops(w[q % W], opnd(co0, SG - 1, q + W), tid);
+        if (q + W < NQ) load_ops_p(w[q % W], opnd(co0, SG - 1, q + W), tid);
         else load_ops(w[q % W], opnd(co0, SG - 2, q + W - NQ), tid);
         __builtin_amdgcn_sched_barrier(0);
     }
