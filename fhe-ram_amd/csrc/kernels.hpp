@@ -336,6 +336,9 @@ constexpr int BF = FK_BF, BI = FK_BI;
 static_assert(BF <= BMAX && BI <= BMAX, "LDS holds BMAX exchange buffers");
 
 // forward transform of S polynomials, BF at a time
+#ifndef FK_KS_PROLOGUE_EXTRA
+#define FK_KS_PROLOGUE_EXTRA 2   // ks_trace_l: operand polynomials of a step's first pair requested beside the window, behind the forward transforms
+#endif
 #ifndef FK_KS_WINDOW
 #define FK_KS_WINDOW 2    // ks_trace_l: operand polynomials in flight under the transforms (16 registers each; 3: 69 spilled registers, slower)
 #endif
@@ -1283,18 +1286,35 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
     double y1n[E];   // column 1's output Y, on its way to buffer 2 (the next step's mask staging)
 #pragma unroll
     for (int k = 0; k < E; k++) y1n[k] = 0.0;
-    if constexpr (STREAM) {   // the first pair's products: nothing to run under yet (their first KW operands arrived during the forward transforms)
+    if constexpr (STREAM) {
+        // The first pair's products have nothing to run under.  Their first KW operands arrived during the forward transforms; the next KP go into
+        // registers that are free here (no pair is being transformed yet: the second accumulator pair's) and are requested at once, the last
+        // NQ - KW - KP into the window as it drains: the wait is one round trip instead of two.
+        constexpr int KP = FK_KS_PROLOGUE_EXTRA;
+        static_assert(KW + KP <= NQ, "prologue window");
+        [[maybe_unused]] OpRegs pw[KP > 0 ? KP : 1];
+#pragma unroll
+        for (int i = 0; i < KP; i++) load_ops_p(pw[i], kopnd(1, SK - 1, KW + i), tid);
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int k = 0; k < E; k++) accn[b][k] = 0.0;
+        // order of use: w[0..KW-1] (polynomials 0..KW-1), pw (KW..KW+KP-1), then the window again (KW+KP..NQ-1)
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            mac_regs(accn[q / SX], xh[q % SX], w[q % KW]);
+            constexpr int dummy = 0; (void)dummy;
+            const bool from_pw = (q >= KW && q < KW + KP);
+            const int slot = (q < KW) ? q : (q - KW - KP) % KW;          // window slot of a polynomial that goes through the window
+            if (from_pw) mac_regs(accn[q / SX], xh[q % SX], pw[(q - KW) < KP && q >= KW ? q - KW : 0]);
+            else mac_regs(accn[q / SX], xh[q % SX], w[slot]);
             pin_regs(accn[q / SX]);
             __builtin_amdgcn_sched_barrier(0);
-            if (q + KW < NQ) load_ops_p(w[q % KW], kopnd(1, SK - 1, q + KW), tid);
-            else load_ops(w[q % KW], kopnd(SK >= 4 ? 1 : 0, SK >= 4 ? SK - 3 : SK - 1, q + KW - NQ), tid);
+            if (!from_pw) {
+                // the slot just drained takes the next polynomial that has no register yet: first the rest of this pair, then the next pair's first KW
+                const int nxt = (q < KW) ? KW + KP + q : q + KW;          // position in the stream (>= NQ: the next pair)
+                if (nxt < NQ) load_ops_p(w[slot], kopnd(1, SK - 1, nxt), tid);
+                else if (nxt - NQ < KW) load_ops(w[(nxt - NQ)], kopnd(SK >= 4 ? 1 : 0, SK >= 4 ? SK - 3 : SK - 1, nxt - NQ), tid);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
