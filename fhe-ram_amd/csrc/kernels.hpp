@@ -311,16 +311,10 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #define FK_EARLY_FETCH 0
 #endif
 #ifndef FK_SPREAD_FETCH
-#define FK_SPREAD_FETCH 1      // ks_trace_y: the next limb's operand loads spread over the post-step (38.8 against 39.7 us per trace step)
+#define FK_SPREAD_FETCH 1      // ks_run: the next limb's operand loads spread over the post-step
 #endif
 #ifndef FK_WARM_OPERANDS
 #define FK_WARM_OPERANDS 0     // ep_run: the first output limb's operands touched in front of the forward transforms (every line: 52.1 against 51.3 us per product; one stripe per polynomial: neutral): off
-#endif
-#ifndef FK_EARLY_FIRST
-#define FK_EARLY_FIRST 0       // ks_trace_y: column 1's first operands requested in front of the forward transforms (fits since FK_LATE_BODY; measured: 38.7-38.9 against 38.5-38.6 us per step: off)
-#endif
-#ifndef FK_LATE_BODY
-#define FK_LATE_BODY 1         // ks_trace_y: the body column of the input fetched and parked at the top of its own limb loop
 #endif
 #ifndef FK_EP_PREFETCH
 #define FK_EP_PREFETCH 0       // ep_run: the first output limb's operands of a column requested ahead of the column loop (75 spilled registers: off)
