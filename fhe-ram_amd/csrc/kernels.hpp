@@ -1119,10 +1119,9 @@ __device__ __forceinline__ double take_digit(double& c) {
 //
 // What it buys: (i) the post-step of an output limb is 1-4 FP64 instructions per coefficient instead of ~9 (+ ~8 for the
 // body column's three digit gathers: the body is gathered ONCE, as Y); (ii) no carry, no running quotient of Y: 32 registers
-// fewer, which pay for (iii) the operands of the next output limbs requested BEFORE the inverse transforms (their fetch —
-// 96 KB per limb through the CU's 64 B/clk address unit, 1 500 cycles — runs under the transforms instead of in front of
-// the MAC) and (iv) TWO inverse transforms at a time (limbs are independent now: no carry chain orders them), which share
-// barriers and LDS round trips as the three forward transforms always did.
+// fewer, which pay for (iii) TWO inverse transforms at a time (limbs are independent now: no carry chain orders them), which share
+// barriers and LDS round trips as the three forward transforms always did, and (iv, round 5) a second accumulator pair and two operand
+// register sets: the operand stream runs under the transforms (ks_trace_l).
 // ---------------------------------------------------------------------------------------
 constexpr double TWO_51 = 2251799813685248.0;          // 2^51
 constexpr double INV_TWO_51 = 1.0 / 2251799813685248.0;
