@@ -25,7 +25,7 @@ _LIB = None
 
 I64P = C.POINTER(C.c_int64)
 
-STATUS = {0: "OK", 1: "INVALID_ARG", 2: "STATE", 3: "UNINITIALIZED", 4: "KEYS", 5: "UNSUPPORTED", 6: "RANGE", 7: "DEVICE"}
+STATUS = {0: "OK", 1: "INVALID_ARG", 2: "STATE", 3: "UNINITIALIZED", 4: "KEYS", 5: "UNSUPPORTED", 6: "RANGE", 7: "DEVICE", 8: "PRECISION"}
 
 
 class FheRamError(RuntimeError):
@@ -43,7 +43,7 @@ class _CParams(C.Structure):
 
 
 _CONFIG_FIELDS = ("limb_split", "fine_split", "memo", "pre_inv", "tail", "tail_test", "mid", "mid_test", "chain", "chain_y", "pair_z",
-                  "fuse", "graph", "safe", "nco", "reserved")
+                  "fuse", "graph", "safe", "nco", "monitor", "reserved")
 
 
 class _CConfig(C.Structure):
@@ -83,6 +83,8 @@ _SYMBOLS = [
     ("fheram_result_download", C.c_int, [C.c_void_p, I64P]),
     ("fheram_result_map", C.c_int, [C.c_void_p, C.POINTER(I64P)]),
     ("fheram_sync", C.c_int, [C.c_void_p]),
+    ("fheram_roundoff_max", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("fheram_roundoff_reset", C.c_int, [C.c_void_p]),
     ("fheram_ctx_create_sharded", C.c_int, [C.POINTER(_CParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("fheram_config_default", None, [C.POINTER(_CConfig)]),
     ("fheram_ctx_create_cfg", C.c_int, [C.POINTER(_CParams), C.c_int, C.c_int, C.c_int, C.POINTER(_CConfig), C.POINTER(C.c_void_p)]),
@@ -146,7 +148,9 @@ _SYMBOLS = [
     ("fheram_group_result_download", C.c_int, [C.c_void_p, I64P]),
     ("fheram_group_peer_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     ("fheram_group_poisoned", C.c_int, [C.c_void_p]),
+    ("fheram_group_roundoff_max", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("fheram_selftest_convolve", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]),
+    ("fheram_selftest_convolve_rounded", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double]),
 ]
 
 
@@ -807,6 +811,19 @@ class Ram:
     def sync(self):
         self._chk(library().fheram_sync(self._h))
 
+    # -- the exactness contract of the FFT64 arithmetic, checked (fheram_roundoff_max)
+    def roundoff_max(self, check: bool = True) -> float:
+        """largest |x - rint(x)| any monitored rounding of an inverse transform has seen on this context since its creation / the
+        last reset; raises FheRamError(8, PRECISION) above 1/4 unless check is False"""
+        m = C.c_double()
+        rc = library().fheram_roundoff_max(self._h, C.byref(m))
+        if rc != 0 and (check or rc != 8):
+            self._chk(rc)
+        return float(m.value)
+
+    def roundoff_reset(self):
+        self._chk(library().fheram_roundoff_reset(self._h))
+
     # -- Poulpy-level ops (parity tests / micro-benchmarks)
     def glwe_external_product(self, a, ggsw):
         a = _i64(a).reshape(-1, self.params.glwe_len())
@@ -895,6 +912,16 @@ class Ram:
         out = np.zeros((2, self.params.n()), dtype=np.float64)
         ip = lambda v: v.ctypes.data_as(C.POINTER(C.c_int32))   # noqa: E731
         self._chk(library().fheram_selftest_convolve(self._h, a.shape[0], ip(a), ip(g), out.ctypes.data_as(C.POINTER(C.c_double)), int(singles)))
+        return out
+
+    def selftest_convolve_rounded(self, a, g, operand_scale: float = 1.0):
+        """the same sums ROUNDED as the path rounds them (through the round-off monitor); operand_scale = 0.5 drives the monitor over its limit"""
+        a = np.ascontiguousarray(a, dtype=np.int32).reshape(-1, self.params.n())
+        g = np.ascontiguousarray(g, dtype=np.int32).reshape(-1, self.params.n())
+        assert a.shape == g.shape
+        out = np.zeros((2, self.params.n()), dtype=np.float64)
+        ip = lambda v: v.ctypes.data_as(C.POINTER(C.c_int32))   # noqa: E731
+        self._chk(library().fheram_selftest_convolve_rounded(self._h, a.shape[0], ip(a), ip(g), out.ctypes.data_as(C.POINTER(C.c_double)), float(operand_scale)))
         return out
 
     def bench_chain(self, kind: int, batch: int, n: int, iters: int) -> float:
@@ -1021,3 +1048,9 @@ class GroupRam:
     def poisoned(self) -> bool:
         """an op failed part-way: every further op is refused until load_encrypted has replaced the rows"""
         return bool(library().fheram_group_poisoned(self._h))
+
+    def roundoff_max(self) -> float:
+        """the largest round-off over the shards' monitors (fheram_group_roundoff_max); raises PRECISION above 1/4"""
+        m = C.c_double()
+        self._chk(library().fheram_group_roundoff_max(self._h, C.byref(m)))
+        return float(m.value)

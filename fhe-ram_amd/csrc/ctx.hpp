@@ -133,6 +133,10 @@ struct fheram_ctx {
     int pair_z = 1;                // FHERAM_PAIR_Z=0: the column-split packer combine with the limb-by-limb normalisation (k_keyswitch<KS_PAIR,...,1>) instead of k_pair_z
     int fuse = 1;                  // FHERAM_FUSE=0: a row's product chain and trace chain as two launches (and the write's elementwise step as a third) instead of k_read_chain / k_write_chain
     int safe = 0;                  // FHERAM_SAFE=1: no in-kernel hand-offs between workgroups, no gate wave (fheram.hip)
+    //  Round-off monitor (fft_dev.hpp mon_note / RoMonitor): every rounding of an inverse transform reports |x - rint(x)|; the
+    //  context's maximum lives behind its twiddle table (d_tw[N]), and a pinned host word is set once it passed MON_LIMIT.
+    int monitor = 1;               // 0: nothing is reported or checked; 1 (default): every coefficient of every rounding
+    unsigned* h_ro_flag = nullptr; // pinned, device-visible: 1 = a round-off above MON_LIMIT was seen (sticky until fheram_roundoff_reset)
     int pre_inv = 1;
     uint64_t inv_id[2] = {0, 0};
     double* d_prep_inv = nullptr;  // [n_digits] prepared GGSW
@@ -195,6 +199,12 @@ namespace {
 int fail(fheram_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg; else g_create_err = msg;
     return code;
+}
+// Called wherever the host has just waited for the device: the sticky flag of the round-off monitor turns into a status.
+int check_precision(fheram_ctx* c) {
+    if (c->h_ro_flag && __atomic_load_n(c->h_ro_flag, __ATOMIC_RELAXED))
+        return fail(c, FHERAM_ERR_PRECISION, "FP64 round-off of an inverse transform exceeded 1/4 (fheram_roundoff_max): the rounded integers are no longer trustworthy");
+    return FHERAM_OK;
 }
 #define HIPCHK(c, call)                                                                     \
     do {                                                                                    \

@@ -8,8 +8,10 @@
 // folded into the prepared operands.  Every product on the RAM path is an exact integer negacyclic convolution of
 // normalised 17-bit limbs bounded by 6 * 4096 * 2^32 < 2^47; the inverse transform's output is rounded to
 // the nearest integer, which is that integer as long as the accumulated FP64 round-off stays below 1/2 — the reference
-// backend's own contract.  Measured round-off (tests/test_gpu_fft.py, tools/fft_bench.hip): <= 2^-9 on uniformly random
-// limbs at any magnitude, 0.125 on the worst coherent pattern (every coefficient -2^16, six terms).
+// backend's own contract.  Measured round-off (tests/test_gpu_fft.py, tools/fft_search.hip): <= 2^-9 on uniformly random
+// limbs at any magnitude, 0.125 on the worst coherent pattern (every coefficient -2^16, six terms).  No a-priori bound below
+// 1/2 is known for six terms of extreme limbs, so the contract is CHECKED: every rounding of an inverse transform feeds a
+// round-off monitor (mon_note / RoMonitor below), whose maximum the host reads back and turns into FHERAM_ERR_PRECISION.
 //
 // Decomposition: one 512-thread workgroup (8 waves) per polynomial, 4 complex points (= 8 coefficients) per thread, i.e. two
 // index bits in registers.  A swap round (v_permlane32_swap / v_permlane16_swap: one instruction per register pair) trades a
@@ -41,7 +43,16 @@ constexpr int NC = N / 2;        // complex points per polynomial
 constexpr int LDS_TW = N;        // doubles: NC complex twiddles W[h] = (re, im), heap order (W[0] unused)
 constexpr int LDS_DATA = N + N / E;  // doubles per polynomial exchange buffer: 2304 complex incl. padding
 constexpr int BMAX = 3;          // exchange buffers (a pair transform uses two, a single one)
-constexpr size_t LDS_BYTES = (size_t)(LDS_TW + BMAX * LDS_DATA) * sizeof(double);
+constexpr int LDS_MON = T;       // doubles: one slot per thread for the round-off monitor (behind the exchange buffers)
+constexpr int MON_OFF = LDS_TW + BMAX * LDS_DATA;
+constexpr size_t LDS_BYTES = (size_t)(LDS_TW + BMAX * LDS_DATA + LDS_MON) * sizeof(double);
+// The twiddle table in global memory is N doubles followed by the monitor's two words (one table per context):
+//   [0]      slot of W[0], which the recursion never reads: its FIRST DWORD is the monitor mode (0: nothing is reported, 1: on);
+//            [1] stays 0.0 (its upper dword is the split barrier's counter in LDS)
+//   [N]      max |x - rint(x)| over every monitored rounding so far, as the bits of a non-negative double (unsigned max)
+//   [N + 1]  device-visible address of a pinned host word that is set to 1 once a round-off above MON_LIMIT was seen
+constexpr int TW_GLOBAL = N + 2;
+constexpr double MON_LIMIT = 0.25;
 
 typedef double d2 __attribute__((ext_vector_type(2)));   // (re, im)
 
@@ -70,11 +81,14 @@ __device__ __forceinline__ void wave_lds_fence() {
 // says "every wave has finished reading the previous batch's buffers across waves" — and the wave that gets there first has a fold,
 // operand loads and six polynomial products to do before it stores into those buffers again.  So: ARRIVE (one LDS add by lane 0)
 // behind the wave's last cross-wave load of a batch, WAIT (poll one LDS word) in front of the next batch's first store.  The
-// counter is dword 3 of twiddle slot 0 (never a twiddle: twpos >= 1; zeroed by the table copy, whose __syncthreads publishes it).
+// counter is dword 3 of twiddle slot 0 (never a twiddle: twpos >= 1; zeroed explicitly by both table copies below — load_twiddles,
+// twiddles_commit — whose __syncthreads publishes it; every kernel runs one of them before its first FENCE == 2 transform).
 // LDS operations of a wave execute in order, so the arrival is performed behind the loads it stands for.  The counter only grows,
 // and a wave arrives for batch m + 1 behind that batch's rendezvous barrier, which every wave reaches behind its own arrival for
 // batch m: arrivals come in rounds of eight, and "a multiple of eight" means "every wave has arrived for every batch so far" — no
 // state is carried between calls.  (The rendezvous inside a transform stays the hardware barrier: polling it was measured slower.)
+static_assert(T / 64 == 8, "sb_wait_free counts arrivals in rounds of T / 64 waves with a power-of-two mask");
+constexpr unsigned SB_WAVES = T / 64;
 __device__ __forceinline__ unsigned sb_addr(const double* tw) { return (unsigned)(size_t)tw + 12u; }
 __device__ __forceinline__ bool sb_lane0() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u; }
 __device__ __forceinline__ void sb_arrive_free(unsigned a) {
@@ -84,7 +98,7 @@ __device__ __forceinline__ void sb_wait_free(unsigned a) {
     for (;;) {
         unsigned v;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-        if ((__builtin_amdgcn_readfirstlane(v) & 7u) == 0u) break;
+        if ((__builtin_amdgcn_readfirstlane(v) & (SB_WAVES - 1u)) == 0u) break;
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -269,13 +283,71 @@ __device__ __forceinline__ void nat_in(d2 (&y)[4], const double (&a)[E]) {
 #pragma unroll
     for (int k = 0; k < 4; k++) { y[k].x = a[k]; y[k].y = a[k + 4]; }
 }
+// ---- round-off monitor ------------------------------------------------------------------------------------------------------------
+// The rounded output of an inverse transform is the exact integer only while the accumulated FP64 round-off stays below 1/2.
+// Every rounding on the path reports max |x - rint(x)| over the thread's eight coefficients into the thread's own LDS slot
+// (ds_max on the bits of a non-negative double: no return value, nothing waits for it, no branch: ~16 FP64 instructions
+// beside the ~180 of the transform); RoMonitor, constructed at the top of every kernel that rounds, folds the slots into the
+// context's maximum when the kernel ends — one comparison per wave against the value the kernel started from (a scalar load at
+// kernel start), one global atomic only from a wave that raises it.  Measured: 0.3 % of a step (profiles/r06_experiments.txt).
+#ifndef FK_MONITOR
+#define FK_MONITOR 1     // 0: compiled out (A/B measurements only)
+#endif
+__device__ __forceinline__ void mon_note(const double* tw_lds, int tid, const d2 (&y)[4], const double (&a)[E]) {
+#if FK_MONITOR
+    double m = __builtin_fmax(__builtin_fabs(y[0].x - a[0]), __builtin_fabs(y[0].y - a[4]));
+#pragma unroll
+    for (int k = 1; k < 4; k++) m = __builtin_fmax(m, __builtin_fmax(__builtin_fabs(y[k].x - a[k]), __builtin_fabs(y[k].y - a[k + 4])));
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(const_cast<double*>(tw_lds) + MON_OFF + tid);
+    __hip_atomic_fetch_max(slot, (unsigned long long)__double_as_longlong(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
+}
+struct RoMonitor {
+    double* lds_;
+    const double* twg_;
+    unsigned long long seen_;   // the context's maximum when this kernel started (wave uniform: scalar registers)
+    bool on_;
+    // lds: the kernel's dynamic LDS (LDS_BYTES); tw_g: the context's table in global memory; on = false: a kernel variant without LDS
+    __device__ __forceinline__ RoMonitor(double* lds, const double* tw_g, bool on = true) : lds_(lds), twg_(tw_g), seen_(~0ull), on_(on) {
+#if FK_MONITOR
+        if (on_) {
+            lds_[MON_OFF + vt((int)threadIdx.x)] = 0.0;     // thread-private: no barrier between this, mon_note and the flush
+            // mode 0 (first dword of the table): nothing is ever reported.  Both words are wave uniform: scalar loads, in flight
+            // while the kernel starts up.
+            const unsigned mode = reinterpret_cast<const unsigned*>(tw_g)[0];
+            const unsigned long long seen = reinterpret_cast<const unsigned long long*>(tw_g)[N];
+            seen_ = mode ? seen : ~0ull;
+        }
+#endif
+    }
+    __device__ __forceinline__ ~RoMonitor() {
+#if FK_MONITOR
+        if (!on_) return;
+        unsigned long long b = (unsigned long long)__double_as_longlong(lds_[MON_OFF + vt((int)threadIdx.x)]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = (unsigned long long)__shfl_xor((long long)b, off, 64);
+            b = o > b ? o : b;
+        }
+        if (b > seen_ && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
+            unsigned long long* gmax = reinterpret_cast<unsigned long long*>(const_cast<double*>(twg_) + N);
+            __hip_atomic_fetch_max(gmax, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__longlong_as_double((long long)b) > MON_LIMIT) {
+                unsigned* hflag = reinterpret_cast<unsigned*>((size_t)__double_as_longlong(twg_[N + 1]));
+                if (hflag) __hip_atomic_store(hflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+#endif
+    }
+};
 template <bool ROUND = true>
-__device__ __forceinline__ void nat_out(const d2 (&y)[4], double (&a)[E]) {
+__device__ __forceinline__ void nat_out(const d2 (&y)[4], double (&a)[E], const double* tw_lds, int tid) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if constexpr (ROUND) { a[k] = __builtin_rint(y[k].x); a[k + 4] = __builtin_rint(y[k].y); }
         else { a[k] = y[k].x; a[k + 4] = y[k].y; }   // (round-off measurements only)
     }
+    if constexpr (ROUND) mon_note(tw_lds, tid, y, a);
 }
 __device__ __forceinline__ void dom_in(d2 (&y)[4], const double (&a)[E]) {
 #pragma unroll
@@ -355,7 +427,7 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
 #pragma unroll
     for (int b = 0; b < B; b++) x0a_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
 #pragma unroll
-    for (int b = 0; b < B; b++) { i_pass3(y[b], t0); nat_out<ROUND>(y[b], x[b]); }
+    for (int b = 0; b < B; b++) { i_pass3(y[b], t0); nat_out<ROUND>(y[b], x[b], tw_, tid); }
     if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
 }
 
@@ -399,7 +471,7 @@ __device__ __forceinline__ void fft_inv1_hooked(double (&x)[1][E], const double*
     __builtin_amdgcn_sched_barrier(0);
     hook(std::integral_constant<int, 3>{});
     __builtin_amdgcn_sched_barrier(0);
-    nat_out<ROUND>(y, x[0]);
+    nat_out<ROUND>(y, x[0], tw_, tid);
 }
 
 // ---- TWO inverse transforms half a phase apart with work of the caller's between their phases (six places) ------------------------------
@@ -433,9 +505,9 @@ __device__ __forceinline__ void fft_inv2_hooked(double (&x)[2][E], const double*
     x0a_r(y[0], buf[0], xa);
     x0a_r(y[1], buf[1], xa);
     FK_HOOK(4);
-    i_pass3(y[0], t0); nat_out<true>(y[0], x[0]);
+    i_pass3(y[0], t0); nat_out<true>(y[0], x[0], tw_, tid);
     FK_HOOK(5);
-    i_pass3(y[1], t0); nat_out<true>(y[1], x[1]);
+    i_pass3(y[1], t0); nat_out<true>(y[1], x[1], tw_, tid);
 #undef FK_HOOK
     if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
 }
@@ -448,14 +520,13 @@ __device__ __forceinline__ void ntt_fwd(double (&x)[B][E], const double* tw, dou
     if constexpr (B == 2) { double* const d[2] = {data, data + LDS_DATA}; fft_fwd_skew<2>(x, tw, d, tid); }
     if constexpr (B == 3) { double* const d[3] = {data, data + LDS_DATA, data + 2 * LDS_DATA}; fft_fwd_skew<3>(x, tw, d, tid); }
 }
-// PRE is accepted for the call sites' sake (the modular transform had an initial reduction); unused.
-template <int B, bool FENCE = true, bool PRE = true>
+template <int B, bool FENCE = true>
 __device__ __forceinline__ void ntt_inv(double (&x)[B][E], const double* tw, double* data, int tid) {
     static_assert(B >= 1 && B <= 2, "one or two polynomials");
     if constexpr (B == 1) { double* const d[1] = {data}; fft_inv_skew<1, FENCE ? 1 : 0>(x, tw, d, tid); }
     else { double* const d[2] = {data, data + LDS_DATA}; fft_inv_skew<2, FENCE ? 1 : 0>(x, tw, d, tid); }
 }
-template <bool FENCE = true, bool PRE = true>
+template <bool FENCE = true>
 __device__ __forceinline__ void ntt_inv2_skew(double (&x)[2][E], const double* tw, double* d0, double* d1, int tid) {
     double* const d[2] = {d0, d1};
     fft_inv_skew<2, FENCE ? 1 : 0>(x, tw, d, tid);
@@ -474,7 +545,7 @@ __device__ __forceinline__ void ntt_fwd3_skew(double (&x)[3][E], const double* t
 // copy the twiddle table (NC complex values) into LDS
 __device__ __forceinline__ void load_twiddles(double* tw_lds, const double* __restrict__ tw_g, int tid) {
 #pragma unroll
-    for (int k = 0; k < E; k++) tw_lds[tid + T * k] = tw_g[tid + T * k];
+    for (int k = 0; k < E; k++) tw_lds[tid + T * k] = (k == 0 && tid == 1) ? 0.0 : tw_g[tid + T * k];   // (slot 0's second double holds the split barrier's counter: zero, whatever the table says)
     __syncthreads();
 }
 // the same in two halves, so that a kernel can issue its coefficient loads between them and pay
@@ -486,7 +557,7 @@ __device__ __forceinline__ void twiddles_issue(TwRegs& r, const double* __restri
 }
 __device__ __forceinline__ void twiddles_commit(const TwRegs& r, double* tw_lds, int tid) {
 #pragma unroll
-    for (int k = 0; k < E; k++) tw_lds[tid + T * k] = r.v[k];
+    for (int k = 0; k < E; k++) tw_lds[tid + T * k] = (k == 0 && tid == 1) ? 0.0 : r.v[k];   // (see load_twiddles)
     __syncthreads();
 }
 
@@ -539,8 +610,8 @@ __device__ __forceinline__ void rsh1_coeff(const int (&x)[S], int (&y)[S]) {
 #include <cmath>
 #include <vector>
 namespace fk {
-inline std::vector<double> make_fft_twiddles() {   // in the device layout: node h at complex position twpos(h)
-    std::vector<double> tw(N, 0.0);
+inline std::vector<double> make_fft_twiddles() {   // in the device layout: node h at complex position twpos(h); [N], [N + 1]: the monitor's words (zero)
+    std::vector<double> tw(TW_GLOBAL, 0.0);
     std::vector<long double> a(NC, 0.0L);   // angle / pi: dyadic rationals with at most 13 fractional bits, exact
     a[1] = 0.25L;
     const long double pi = 3.14159265358979323846264338327950288L;

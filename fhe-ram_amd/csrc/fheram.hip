@@ -26,7 +26,7 @@ void fheram_config_default(fheram_config* cfg) {
     if (!cfg) return;
     fheram_config d{};
     d.limb_split = 1; d.fine_split = 1; d.memo = 1; d.pre_inv = 1; d.tail = 1; d.tail_test = 0; d.mid = 2; d.mid_test = 0;
-    d.chain = 1; d.chain_y = 3; d.pair_z = 1; d.fuse = 1; d.graph = 0; d.safe = 0; d.nco = 0;
+    d.chain = 1; d.chain_y = 3; d.pair_z = 1; d.fuse = 1; d.graph = 0; d.safe = 0; d.nco = 0; d.monitor = 1; d.reserved = 0;
     auto env = [](const char* n) { const char* v = getenv(n); return (v && v[0]) ? v[0] : '\0'; };
     if (env("FHERAM_LIMB_SPLIT") == '0') d.limb_split = 0;
     if (env("FHERAM_FINE_SPLIT") == '0') d.fine_split = 0;
@@ -46,6 +46,8 @@ void fheram_config_default(fheram_config* cfg) {
     if (env("FHERAM_SAFE") == '1') d.safe = 1;
     const char nc = env("FHERAM_NCO");
     d.nco = nc == '2' ? 2 : (nc == '1' ? 1 : 0);
+    const char mo = env("FHERAM_MONITOR");
+    if (mo == '0') d.monitor = 0;
     *cfg = d;
 }
 
@@ -77,6 +79,8 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
     for (uint32_t i = 0; i < p->n_decomp; i++) { if (p->decomp_n[i] == 0) return fail(nullptr, FHERAM_ERR_INVALID_ARG, "zero digit width"); sum += p->decomp_n[i]; }
     if (sum != p->log_n) return fail(nullptr, FHERAM_ERR_INVALID_ARG, "DECOMP_N must sum to LOG_N (parameters.rs:168)");
     if (p->max_addr > ((uint64_t)N * N)) return fail(nullptr, FHERAM_ERR_UNSUPPORTED, "max_addr > N^2 is not supported by the reference either (SURVEY.md 3.1)");
+    if (user_cfg && user_cfg->reserved != 0)
+        return fail(nullptr, FHERAM_ERR_INVALID_ARG, "fheram_config.reserved must be 0 (start from fheram_config_default())");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -144,7 +148,7 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
         c->tail = cfg.tail ? 1 : 0;
         static std::atomic<int> serial{0};
         c->tail_xoff = ((serial++ + (int)getpid()) & 1) * (TAIL_GROUPS / 2);
-        c->tail_test = cfg.tail_test;
+        c->tail_test = cfg.tail_test < 0 ? 0 : (cfg.tail_test > 2 ? 2 : cfg.tail_test);
         c->mid = cfg.mid < 0 ? 0 : (cfg.mid > 2 ? 2 : cfg.mid);   // 1: the <= 16 ciphertext split only
         c->mid_test = cfg.mid_test ? 1 : 0;
         c->chain = cfg.chain ? 1 : 0;
@@ -161,6 +165,7 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
         // Same results (tests/test_gpu_golden.py); priced in profiles/r05_bench_safe.json.
         c->safe = cfg.safe ? 1 : 0;
         if (c->safe) { c->tail = 0; c->tail_test = 0; c->mid = 0; c->mid_test = 0; if (c->pre_inv == 1) c->pre_inv = 2; }
+        c->monitor = cfg.monitor ? 1 : 0;   // round-off monitor: on by default (every coefficient of every rounding)
         c->nco = cfg.nco == 2 ? 2 : (cfg.nco == 1 ? 1 : 0);
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
@@ -209,8 +214,16 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
 
     std::vector<double> tw = make_fft_twiddles();
     c->ninv = 1.0 / (double)NC;   // the inverse transform's 1/n, folded into every prepared operand (a power of two: exact)
-    CCHK(hipMalloc(&c->d_tw, N * sizeof(double)));
-    CCHK(hipMemcpy(c->d_tw, tw.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    {   // the round-off monitor's words ride with the table (fft_dev.hpp TW_GLOBAL): mode in the first dword of slot 0, the maximum
+        // at [N], the address of the pinned flag word at [N + 1]
+        CCHK(hipHostMalloc((void**)&c->h_ro_flag, 64, hipHostMallocDefault));
+        *c->h_ro_flag = 0;
+        const uint64_t mode = (uint64_t)c->monitor, flag_addr = (uint64_t)(size_t)c->h_ro_flag;
+        std::memcpy(&tw[0], &mode, 8);
+        std::memcpy(&tw[N + 1], &flag_addr, 8);
+    }
+    CCHK(hipMalloc(&c->d_tw, TW_GLOBAL * sizeof(double)));
+    CCHK(hipMemcpy(c->d_tw, tw.data(), TW_GLOBAL * sizeof(double), hipMemcpyHostToDevice));
     const size_t G = fheram_ctx::GLWE, nrow = (size_t)c->ws * c->rows;
     CCHK(hipMalloc(&c->d_atk, (size_t)LOGN * c->atk * sizeof(double)));
     CCHK(hipMalloc(&c->d_atk_inv, fheram_ctx::EVK5 * sizeof(double)));
@@ -250,7 +263,7 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
     *c->h_tail_fb = 0;
     CCHK(hipHostMalloc((void**)&c->h_mid_fb, 128, hipHostMallocDefault));
     memset(c->h_mid_fb, 0, 128);
-    CCHK(hipHostMalloc((void**)&c->h_res, (size_t)c->ws * G * sizeof(int64_t), hipHostMallocMapped));
+    CCHK(hipHostMalloc((void**)&c->h_res, ((size_t)c->ws * G + 1) * sizeof(int64_t), hipHostMallocMapped));   // + the monitor's maximum at export time
     CCHK(hipHostGetDevicePointer((void**)&c->d_h_res, c->h_res, 0));
     CCHK(hipHostMalloc((void**)&c->h_w, (size_t)c->ws * G * sizeof(int32_t), hipHostMallocDefault));
     CCHK(hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming));
@@ -281,6 +294,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->h_tail_fb) hipHostFree(c->h_tail_fb);
     if (c->h_mid_fb) hipHostFree(c->h_mid_fb);
     if (c->h_res) hipHostFree(c->h_res);
+    if (c->h_ro_flag) hipHostFree(c->h_ro_flag);
     if (c->h_w) hipHostFree(c->h_w);
     if (c->ev_w) hipEventDestroy(c->ev_w);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -292,7 +306,7 @@ int fheram_ctx_config(const fheram_ctx* c, fheram_config* out) {
     fheram_config d{};
     d.limb_split = c->limb_split; d.fine_split = c->fine_split; d.memo = c->memo; d.pre_inv = c->pre_inv; d.tail = c->tail; d.tail_test = c->tail_test;
     d.mid = c->mid; d.mid_test = c->mid_test; d.chain = c->chain; d.chain_y = c->chain_y; d.pair_z = c->pair_z; d.fuse = c->fuse;
-    d.graph = c->use_graph; d.safe = c->safe; d.nco = c->nco;
+    d.graph = c->use_graph; d.safe = c->safe; d.nco = c->nco; d.monitor = c->monitor;
     *out = d;
     return FHERAM_OK;
 }
@@ -357,7 +371,8 @@ int fheram_ram_download(fheram_ctx* c, int64_t* rows) {
     if (!c || !rows) return FHERAM_ERR_INVALID_ARG;
     if (!c->initialized) return fail(c, FHERAM_ERR_UNINITIALIZED, "unitialized memory: self.data.len()=0");
     HIPCHK(c, hipSetDevice(c->device));
-    return download_i64(c, rows, c->d_data, (size_t)c->ws * c->rows * fheram_ctx::GLWE);
+    const int rc = download_i64(c, rows, c->d_data, (size_t)c->ws * c->rows * fheram_ctx::GLWE);
+    return rc == FHERAM_OK ? check_precision(c) : rc;
 }
 int fheram_ram_tree_download(fheram_ctx* c, int level, int64_t* out) {
     if (!c || !out) return FHERAM_ERR_INVALID_ARG;
@@ -397,11 +412,16 @@ int fheram_result_map(fheram_ctx* c, const int64_t** out) {
     HIPCHK(c, hipSetDevice(c->device));
     const int n4 = (int)((size_t)c->ws * fheram_ctx::GLWE / 4);
     hipLaunchKernelGGL(k_export_i64, dim3((n4 + 255) / 256), dim3(256), 0, c->stream, c->d_last_res ? c->d_last_res : c->d_res,
-                       reinterpret_cast<long long*>(c->d_h_res), n4);
+                       reinterpret_cast<long long*>(c->d_h_res), n4, reinterpret_cast<const long long*>(c->d_tw + N));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     *out = c->h_res;
-    return FHERAM_OK;
+    {   // the monitor's maximum as it stood when the result was exported (the export kernel copies it behind the result)
+        double m;
+        std::memcpy(&m, c->h_res + (size_t)c->ws * fheram_ctx::GLWE, 8);
+        if (c->monitor && m > MON_LIMIT) __atomic_store_n(c->h_ro_flag, 1u, __ATOMIC_RELAXED);
+    }
+    return check_precision(c);
 }
 int fheram_result_download(fheram_ctx* c, int64_t* out) {
     if (!c || !out) return FHERAM_ERR_INVALID_ARG;
@@ -416,6 +436,26 @@ int fheram_sync(fheram_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    return check_precision(c);
+}
+int fheram_roundoff_max(fheram_ctx* c, double* max_out) {
+    if (!c || !max_out) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    double m = 0.0;
+    HIPCHK(c, hipMemcpy(&m, c->d_tw + N, sizeof(double), hipMemcpyDeviceToHost));
+    *max_out = m;
+    if (c->monitor && m > MON_LIMIT) __atomic_store_n(c->h_ro_flag, 1u, __ATOMIC_RELAXED);
+    return check_precision(c);
+}
+int fheram_roundoff_reset(fheram_ctx* c) {
+    if (!c) return FHERAM_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    HIPCHK(c, hipMemset(c->d_tw + N, 0, sizeof(double)));
+    __atomic_store_n(c->h_ro_flag, 0u, __ATOMIC_RELAXED);
     return FHERAM_OK;
 }
 
@@ -702,7 +742,7 @@ int fheram_timer_end(fheram_ctx* c, float* ms) {
     HIPCHK(c, hipEventRecord(c->t1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->t1));
     HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
-    return FHERAM_OK;
+    return check_precision(c);
 }
 int fheram_profile_enable(fheram_ctx* c, int on) {
     if (!c) return FHERAM_ERR_INVALID_ARG;

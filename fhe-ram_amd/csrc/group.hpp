@@ -228,6 +228,13 @@ void fheram_group_destroy(fheram_group* g) {
 int fheram_group_create(const fheram_params* p, const int* devices, int n_devices, fheram_group** out) {
     if (!p || !devices || !out || n_devices < 1) return gfail(nullptr, FHERAM_ERR_INVALID_ARG, "null argument / no device");
     *out = nullptr;
+    // context creation, event creation, peer enabling and the self-test all move the calling thread between devices: the caller's
+    // device is read FIRST and restored on every return path
+    struct DeviceRestore {
+        int dev = -1;
+        DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+        ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+    } restore_device;
     fheram_group* g = new fheram_group();
     for (int i = 0; i < n_devices; i++) {
         fheram_ctx* c = nullptr;
@@ -262,8 +269,6 @@ int fheram_group_create(const fheram_params* p, const int* devices, int n_device
     // self-test of the exchange path: one copy shard -> root and one root -> shard per shard, checked word for word.  A pair that
     // cannot copy (no peer path, IOMMU / IPC restrictions) fails HERE, with the pair named, not in the middle of the first read.
     g->peer_direct.assign(n_devices, 1);
-    int dev_before = 0;
-    (void)hipGetDevice(&dev_before);   // the self-test moves the calling thread between devices: restored below
     {
         fheram_ctx* r = g->ctx[g->root];
         const size_t n_probe = 256;
@@ -285,13 +290,11 @@ int fheram_group_create(const fheram_params* p, const int* devices, int n_device
             if (e != hipSuccess || back != pat) {
                 g_group_err = "peer copy self-test failed between device " + std::to_string(devices[i]) + " (shard " + std::to_string(i) + ") and the root's device " +
                               std::to_string(devices[g->root]) + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string(": data mismatch"));
-                (void)hipSetDevice(dev_before);
                 fheram_group_destroy(g);
                 return FHERAM_ERR_DEVICE;
             }
         }
     }
-    (void)hipSetDevice(dev_before);
     for (int i = 0; i < n_devices; i++) {
         g->w.emplace_back(new fheram_group::Worker());
         g->w.back()->th = std::thread(worker_main, g->w.back().get(), devices[i]);
@@ -307,6 +310,21 @@ int fheram_group_peer_info(const fheram_group* g, int* direct, int n) {
     return FHERAM_OK;
 }
 int fheram_group_poisoned(const fheram_group* g) { return (g && g->poisoned) ? 1 : 0; }
+/* max over the shards' round-off monitors (fheram_roundoff_max); FHERAM_ERR_PRECISION if any shard is above the limit */
+int fheram_group_roundoff_max(fheram_group* g, double* out) {
+    if (!g || !out) return FHERAM_ERR_INVALID_ARG;
+    double m = 0.0;
+    int rc = FHERAM_OK;
+    for (int i = 0; i < g->n(); i++) {
+        double v = 0.0;
+        const int r = fheram_roundoff_max(g->ctx[i], &v);
+        if (r != FHERAM_OK && r != FHERAM_ERR_PRECISION) return gfail(g, r, std::string("shard ") + std::to_string(i) + ": " + fheram_last_error(g->ctx[i]));
+        if (r == FHERAM_ERR_PRECISION) rc = r;
+        m = v > m ? v : m;
+    }
+    *out = m;
+    return rc == FHERAM_OK ? rc : gfail(g, rc, "FP64 round-off above the limit on a shard: results are not trustworthy");
+}
 
 /* EvaluationKeysPrepared::prepare on every shard (keys are replicated; keys.rs:57-71) */
 int fheram_group_keys_load(fheram_group* g, const int64_t* gal_els, int n_gal, const int64_t* const* atk_glwe,

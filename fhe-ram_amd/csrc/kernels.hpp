@@ -14,8 +14,9 @@
 //
 // Device GLWE layout: int32 [limb][col][N] (the host's int64 layout narrowed; limbs are
 // normalised to 17 bits so nothing is lost).  Prepared operands: double, transform domain,
-// scaled by 1/N, stored so that thread t's elements (2kk, 2kk+1) are one 16-byte word at
-// [kk*T + t] (coalesced 16 B/lane loads).
+// scaled by 1/n (n = N/2 complex points: the inverse transform's factor), stored so that thread t's
+// elements (2kk, 2kk+1) are one 16-byte word at [kk*T + t] (coalesced 16 B/lane loads).
+// Every kernel that rounds the output of an inverse transform constructs a RoMonitor (fft_dev.hpp) first.
 #pragma once
 #include "fft_dev.hpp"
 #include <type_traits>
@@ -570,6 +571,7 @@ template <int SA, int SG, int NCO, int STAGE = 0>
 __global__ __launch_bounds__(T, T / 256) void k_ext_product(GlweRef a, GlweRef res, const double* __restrict__ ggsw,
                                                             const double* __restrict__ tw_g, double* __restrict__ big) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, tw_g, STAGE != 2);
     ep_run<SA, SG, NCO, STAGE>(a, res, ggsw, tw_g, big, lds, true, vt((int)threadIdx.x));
 }
 // CoordinatePrepared::product(_inplace) (coordinate_prepared.rs:147-177) as ONE launch: the n external products
@@ -591,6 +593,7 @@ struct EpChainArgs {
 template <int SA, int SG>
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_ext_product_chain(EpChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, ca.tw);
     if (ca.done) {
         if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
         if (threadIdx.x == 0) {
@@ -1005,7 +1008,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
             fetch(j);
             double acc[1][E];
             mac(acc[0], -1);
-            ntt_inv<1, false, (SX > 3)>(acc, tw, data, tid);   // the only inverse transform of this workgroup
+            ntt_inv<1, false>(acc, tw, data, tid);   // the only inverse transform of this workgroup
             add_body(acc[0], j);
             double* bgp = ka.big + big_ct() + (long)(co * SK + j) * N;
 #pragma unroll
@@ -1029,7 +1032,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
                 if (j - KBI >= 0) fetch(j - KBI);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            ntt_inv<KBI, !DB, (SX > 3)>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);   // <= 3 MAC terms: no initial reduce
+            ntt_inv<KBI, !DB>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
             if constexpr (FK_EARLY_FETCH == 0 && FK_SPREAD_FETCH && KBI == 1 && SX == 3) {
                 // next limb's operands: their latency overlaps the post-step; one operand polynomial at a time around its parts (see
                 // ks_trace_y: twelve loads per thread from all waves at once queue at the address unit)
@@ -1060,7 +1063,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
         if constexpr (REM == 1) {
             double acc[1][E];
             mac(acc[0], -1);
-            ntt_inv<1, !DB, (SX > 3)>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
+            ntt_inv<1, !DB>(acc, tw, data + (DB ? (it++ & 1) * KBI * LDS_DATA : 0), tid);
             add_body(acc[0], 0);
             emit(acc[0], 0);
         }
@@ -1070,6 +1073,7 @@ __device__ __forceinline__ void ks_run(const KsArgs& ka, double* lds, bool load_
 template <int MODE, int SX, int SK, int SO, int NCO, int STAGE = 0>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch(KsArgs ka) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, ka.tw, STAGE != 2);
     ks_run<MODE, SX, SK, SO, NCO, STAGE>(ka, lds, true, vt((int)threadIdx.x));
 }
 // ---------------------------------------------------------------------------------------
@@ -1178,8 +1182,9 @@ __device__ __forceinline__ void fold_limb4(double (&od)[E], const double (&acc)[
 // inverse transforms.  No global loads or stores between the steps (round 3's register hand-over kept the global round trip
 // of the gathers' staging; here it is gone), no store drain at a step's end, and one workgroup barrier fewer per step.
 //   IN_Y  : the input comes that way (else: an int32 GLWE, first step)    OUT_Y : the output leaves that way (else int32, last step)
-// Round 5: for an even limb count the 2 * SK * SX operand polynomials of a step (768 KB at SK = 4) stream under the pairs of inverse
-// transforms (fft_inv2_hooked): the products of the next pair of output limbs are taken between the phases of this pair's transforms.
+// Round 5: the 2 * SK * SX operand polynomials of a step (768 KB at SK = 4) stream under the pairs of inverse transforms
+// (fft_inv2_hooked): the products of the next pair of output limbs are taken between the phases of this pair's transforms.  Round 6: the
+// same for five limbs (pairs + one: the lone limb's products under the previous pair's transforms, the next column's first under its own).
 // ---------------------------------------------------------------------------------------
 //   OUT2: (k_write_chain) the last trace step of write_mid_step hands normalize(ct_hi - trace(ct_hi) + trace(ct_lo X^-row)) (ram.rs:617,625-626)
 //   to write_last_step's products: ka.b = the row (ct_hi), ka.out = trace(ct_hi); the result leaves as A (not Y), the mask column in
@@ -1250,14 +1255,8 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
             sidx = (sidx + sstep) & (2 * N - 1);
         }
     }
-    // operands of the first output limb of column 1: in flight during the forward transforms
-    OpRegs g[SX];
-    auto fetch = [&](int j, int co, int r0, int r1) {
-#pragma unroll
-        for (int r = 0; r < SX; r++)
-            if (r >= r0 && r < r1) load_ops(g[r], ka.key + (long)((r * SK + j) * 2 + co) * N, tid);
-    };
-    constexpr bool STREAM = !(SK & 1);   // (an odd limb count — the README block's keys — keeps the unstreamed pairs + one)
+    constexpr bool STREAM = true;        // (round 6: odd limb counts — the README block's 5-limb keys — stream too: pairs + one, see below)
+    static_assert(!(SK & 1) || SK == 5, "odd limb counts: the pairs-plus-one schedule below is written out for five limbs");
     constexpr int KW = FK_KS_WINDOW, NQ = 2 * SX;
     [[maybe_unused]] OpRegs w[STREAM ? KW : 1];
     [[maybe_unused]] double accn[2][E];
@@ -1334,46 +1333,58 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         }
 #pragma unroll
         for (int k = 0; k < E; k++) ec[k] = 0.0;
-        if (!STREAM) fetch(SK - 1, co, 0, SX);
-        if constexpr (SK & 1) {   // odd limb count: pairs, then the last limb on its own (peeled: one path per loop body)
-        // one batch of NB output limbs (j, j-1): products, inverse transforms, fold
-        auto batch = [&](auto nb_tag, int j) {
-            constexpr int NB = decltype(nb_tag)::value;
+        if constexpr (SK & 1) {
+        // Five limbs: pairs (4,3), (2,1) and limb 0 on its own, per column: six units per step.  The operand stream is ONE sequence of
+        // 2 * 15 polynomials (column 1 first; per column limb 4 digit rows 0..2, limb 3, ... limb 0): position p -> column p < 15 ? 1 : 0,
+        // limb 4 - (p % 15) / 3, digit row p % 3, register set p % KW.  The products of positions 0..5 (column 1's first pair) were taken
+        // in the prologue above; every later product is taken between the phases of an EARLIER unit's transforms: a pair's transforms
+        // (fft_inv2_hooked, six places) host the next six positions, the lone limb's (fft_inv1_hooked) the next three — so while the
+        // lone limb of column 1 is summed into accn[0], accn[1] already takes limb 4 of column 0, and limb 3 goes to accn[0] under the
+        // lone limb's own transform (the pair then arrives swapped: SWAP).
+        constexpr int NTOT = 2 * SK * SX;
+        [[maybe_unused]] auto kop = [&](int p_) { return kopnd(p_ < SK * SX ? 1 : 0, SK - 1, p_ % (SK * SX)); };
+        auto unit = [&](auto nb_tag, auto p_tag, auto nh_tag, auto swap_tag, auto j_tag) {
+            constexpr int NB = decltype(nb_tag)::value, P = decltype(p_tag)::value, NH = decltype(nh_tag)::value, J = decltype(j_tag)::value;
+            constexpr bool SWAP = decltype(swap_tag)::value;
             double acc[NB][E];
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int k = 0; k < E; k++) acc[b][k] = 0.0;
-            // limb j from the operands in flight; each register set is refilled with limb j-1's as soon as it has been used
-#pragma unroll
-            for (int r = 0; r < SX; r++) {
-                mac_regs(acc[0], xh[r], g[r]);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (NB == 2) load_ops(g[r], ka.key + (long)((r * SK + (j - 1)) * 2 + co) * N, tid);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if constexpr (NB == 2) {
 #pragma unroll
-                for (int r = 0; r < SX; r++) mac_regs(acc[NB - 1], xh[r], g[r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
-            if constexpr (NB == 2) {
-                ntt_inv2_loop(acc, tw, data, data + LDS_DATA, tid);
-                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                fold_limb<SK>(od, ec, acc[0], j);
-                fold_limb<SK>(od, ec, acc[NB - 1], j - 1);
+                for (int k = 0; k < E; k++) { acc[0][k] = accn[SWAP ? 1 : 0][k]; acc[1][k] = accn[SWAP ? 0 : 1][k]; accn[0][k] = 0.0; accn[1][k] = 0.0; }
             } else {
-                ntt_inv1_loop(acc, tw, data, tid);
-                YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
-                fold_limb<SK>(od, ec, acc[0], j);
+#pragma unroll
+                for (int k = 0; k < E; k++) { acc[0][k] = accn[0][k]; accn[0][k] = 0.0; }      // (accn[1] may hold the next column's first limb)
             }
-            if (j >= NB) fetch(j - NB, co, 0, SX);   // the next limbs' operands: their fetch runs under the first products
-            YSTAMP(11 + (ci * SK + (SK - 1 - j)) * 4);
+            auto hook = [&](auto stag) {
+                constexpr int sl = decltype(stag)::value;
+                if constexpr (sl < NH) {
+                    constexpr int pp = P + sl;
+                    mac_regs(accn[sl / SX], xh[pp % SX], w[pp % KW]);
+                    pin_regs(accn[sl / SX]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (pp + KW < NTOT) load_ops(w[pp % KW], kop(pp + KW), tid);
+                }
+            };
+            if constexpr (NB == 2) {
+                fft_inv2_hooked<2>(acc, tw, data, data + LDS_DATA, tid, hook);
+                fold_limb<SK>(od, ec, acc[0], J);
+                fold_limb<SK>(od, ec, acc[1], J - 1);
+            } else {
+                fft_inv1_hooked<2>(acc, tw, data, tid, hook);
+                fold_limb<SK>(od, ec, acc[0], J);
+            }
         };
-#pragma unroll 1
-        for (int j = SK - 1; j >= 1; j -= 2) batch(std::integral_constant<int, 2>{}, j);
-        batch(std::integral_constant<int, 1>{}, 0);
+        using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
+        if (ci == 0) {
+            unit(integral_constant<int, 2>{}, integral_constant<int, 6>{}, integral_constant<int, 6>{}, false_type{}, integral_constant<int, 4>{});
+            unit(integral_constant<int, 2>{}, integral_constant<int, 12>{}, integral_constant<int, 6>{}, false_type{}, integral_constant<int, 2>{});
+            unit(integral_constant<int, 1>{}, integral_constant<int, 18>{}, integral_constant<int, 3>{}, false_type{}, integral_constant<int, 0>{});
+        } else {
+            unit(integral_constant<int, 2>{}, integral_constant<int, 21>{}, integral_constant<int, 6>{}, true_type{}, integral_constant<int, 4>{});
+            unit(integral_constant<int, 2>{}, integral_constant<int, 27>{}, integral_constant<int, 3>{}, false_type{}, integral_constant<int, 2>{});
+            unit(integral_constant<int, 1>{}, integral_constant<int, 30>{}, integral_constant<int, 0>{}, false_type{}, integral_constant<int, 0>{});
+        }
         } else {
         // The operand stream under the inverse transforms: the six products of the NEXT pair of output limbs are taken between the phases of
         // this pair's transforms (fft_inv2_hooked), each from a register set that is refilled at once with the polynomial W places further on in
@@ -1452,7 +1463,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
 // thread only (no gather: the external product has no automorphism), so the hand-over needs no barrier at all: the result
 // travels as A = the integer whose balanced base-2^17 digits are the three output limbs (closed-form normalisation, see
 // ks_trace_z: one accumulator per coefficient, no carry chain), column 1 in registers (ac), column 0 — finished first — in
-// this wave's own region of the third exchange buffer, which the inverse transforms leave alone.  The consumer takes its digits
+// thread-private slots of the third exchange buffer (`park`), which the inverse transforms leave alone.  The consumer takes its digits
 // with take_digit.  The operand stream runs under the transforms (round 5: see the comment at the first request below).
 //   IN_R : the input comes that way (else an int32 GLWE: first product)     OUT_R : the output leaves that way (else int32: last)
 // ---------------------------------------------------------------------------------------
@@ -1472,7 +1483,7 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
     if (load_tw) twiddles_issue(twr, tw_g, tid);
     const int32_t* ap = at(a);
     int32_t* rp = at(res);
-    double* park = data + 2 * LDS_DATA + (tid >> 6) * (64 * (E + 1)) + (tid & 63);   // this wave's own region of buffer 2
+    double* park = data + 2 * LDS_DATA + (tid >> 6) * (64 * (E + 1)) + (tid & 63);   // thread-private slots of buffer 2 (tid is the VIRTUAL id: a (tid >> 6) group spans two hardware waves, which is harmless because no slot is shared)
     double x0[SA][E], x1[SA][E];
     auto digits_of = [&](const double (&av)[E], double (&x)[SA][E]) {
 #pragma unroll
@@ -1646,6 +1657,7 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
 template <int SG>
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_ext_product_chain_r(EpChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, ca.tw);
     GlweRef in = ca.src;
     double ac[E];
 #pragma unroll
@@ -1692,6 +1704,7 @@ struct KsChainArgs {
 template <int SX, int SK, int SO, int YF = 0>   // YF: 0 int32 limbs between the steps (ks_run); 3 the intermediates as Y = ceil(A/2) with the closed-form normalisation, handed over through LDS and registers (ks_trace_l)
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_keyswitch_chain(KsChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, ca.base.tw);
     if (ca.pred) {
         if (__hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -1750,6 +1763,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
 template <int SK>
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_pair_z(KsArgs ka) {   // (capped as the chain kernels: the first pair level of read_prepare_write is 256 workgroups beside the gate wave)
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, ka.tw);
     static_assert((SK & 1) == 0 || SK == 5, "pairs of output limbs (+ one)");
     constexpr int SX = 3;
     const int tid = vt((int)threadIdx.x);
@@ -1890,6 +1904,7 @@ struct RowChainArgs {
 template <int SK, int SG>
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_read_chain(RowChainArgs ra) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, ra.ep.tw);
     double vc[E];
 #pragma unroll
     for (int k = 0; k < E; k++) vc[k] = 0.0;
@@ -1923,6 +1938,7 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN
 template <int SK, int SG>
 __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_write_chain(RowChainArgs ra) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, ra.ep.tw);
     double vc[E];   // (written by the first step before anything reads it)
     KsArgs ka = ra.ks.base;
 #pragma unroll 1
@@ -2058,6 +2074,7 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)   // the last block: every block of the launch has been placed (k_tail_gate)
         __hip_atomic_store(ta.sync + TAIL_GROUPS * 32 + 2, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (g >= ta.n_ct) return;
+    RoMonitor ro_mon(lds, ta.tw);
     const int tid = vt((int)threadIdx.x);
     double* tw = lds;
     double* data = lds + LDS_TW;
@@ -2135,7 +2152,7 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
         for (int k = 0; k < E; k++) acc[0][k] = 0.0;
         mac_regs(acc[0], x[0], kop);
         if (!last) load_ops(kop, ta.key[s + 1] + (long)((r * SK + j) * 2 + co) * N, tid);   // arrives during the rest of the step
-        ntt_inv<1, false, false>(acc, tw, data, tid);
+        ntt_inv<1, false>(acc, tw, data, tid);
         TSTAMP(3);
         {
             double* bgp = bigg + (long)((co * SK + j) * SX + r) * N;
@@ -2270,6 +2287,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ntt_probe(const double* __restri
 template <int MODE, int SX, int SK>
 __global__ __launch_bounds__(T, T / 256) void k_keyswitch_fine(KsArgs ka) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, ka.tw);
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = vt((int)threadIdx.x);
@@ -2351,7 +2369,7 @@ __global__ __launch_bounds__(T, T / 256) void k_keyswitch_fine(KsArgs ka) {
     for (int k = 0; k < E; k++) acc[0][k] = 0.0;
     mac_regs(acc[0], x[0], g);
     STAMPZ(5);
-    ntt_inv<1, false, false>(acc, tw, data, tid);
+    ntt_inv<1, false>(acc, tw, data, tid);
     STAMPZ(6);
 #pragma unroll
     for (int k = 0; k < E; k++) acc[0][k] += (double)bodyv[k];
@@ -2366,6 +2384,7 @@ template <int SA, int SG>
 __global__ __launch_bounds__(T, T / 256) void k_ext_product_fine(GlweRef a, const double* __restrict__ ggsw,
                                                                  const double* __restrict__ tw_g, double* __restrict__ big) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, tw_g);
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = vt((int)threadIdx.x);
@@ -2386,7 +2405,7 @@ __global__ __launch_bounds__(T, T / 256) void k_ext_product_fine(GlweRef a, cons
 #pragma unroll
     for (int k = 0; k < E; k++) acc[0][k] = 0.0;
     mac_regs(acc[0], x[0], g);
-    ntt_inv<1, false, false>(acc, tw, data, tid);
+    ntt_inv<1, false>(acc, tw, data, tid);
     double* bp = big + big_ct() * (2 * SA) + (long)((co * SG + j) * 2 * SA + cin * SA + r) * N;
 #pragma unroll
     for (int k = 0; k < E; k++) bp[tid + T * k] = acc[0][k];
@@ -2586,6 +2605,7 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
     const int slot = bi / MEMBERS, m = bi % MEMBERS;
     const int ctg = slot * 8 + xcd;            // ciphertext (group) of this workgroup
     if (slot >= GPX || ctg >= ma.n_ct) return;
+    RoMonitor ro_mon(lds, ma.tw);
     const int tid0 = vt((int)threadIdx.x);
     int tid = tid0;
     const int r = m % RS, h = m / RS;          // input digit (RS == 1: all three); output limb polynomials h * LPM + l
@@ -2714,9 +2734,8 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
             __builtin_amdgcn_sched_barrier(0);
             if (l + 1 < LPM) fetch(s, l + 1);  // arrives during the inverse transform
             else if (!last) fetch(s + 1, 0);   // the next step's first operands: they arrive during the hand-offs
-            // at most three MAC terms: no initial reduction; buffer l % 2: alternating, and the previous transform in buffers 0 and 1
-            // was a forward one (fenced inside) or none
-            ntt_inv<1, false, false>(acc, tw, data + (l & 1) * LDS_DATA, tid);
+            // buffer l % 2: alternating, and the previous transform in buffers 0 and 1 was a forward one (fenced inside) or none
+            ntt_inv<1, false>(acc, tw, data + (l & 1) * LDS_DATA, tid);
             double* bgp = bigg + (long)((co * SK + j) * RS + r) * N;
 #pragma unroll
             for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
@@ -2851,8 +2870,10 @@ __global__ __launch_bounds__(T, T / 256) void k_chain_mid(MidArgs ma) {
 }
 
 // int32 device limbs -> int64 host layout, written straight into pinned host memory (the result of a read)
-__global__ __launch_bounds__(256) void k_export_i64(const int32_t* __restrict__ src, long long* __restrict__ dst, int n4) {
+// mon: the round-off monitor's maximum (fft_dev.hpp), copied behind the result: the host sees it with the result, for free
+__global__ __launch_bounds__(256) void k_export_i64(const int32_t* __restrict__ src, long long* __restrict__ dst, int n4, const long long* mon) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) dst[4 * (long)n4] = __hip_atomic_load(mon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i >= n4) return;
     const int4 v = reinterpret_cast<const int4*>(src)[i];
     longlong2 a, b;
@@ -2931,6 +2952,7 @@ template <int S, int DEC>
 __global__ __launch_bounds__(T, T / 256) void k_encrypt_sk(int32_t* __restrict__ cts, const double* __restrict__ s_hat,
                                                            const double* __restrict__ tw_g, const int32_t* __restrict__ pt1) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, tw_g);
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = vt((int)threadIdx.x);
@@ -2954,7 +2976,7 @@ __global__ __launch_bounds__(T, T / 256) void k_encrypt_sk(int32_t* __restrict__
         for (int k = 0; k < E; k++) { x[0][k] = (double)mi[k]; acc[0][k] = 0.0; }
         ntt_fwd<1>(x, tw, data, tid);
         mac_regs(acc[0], x[0], sh);
-        ntt_inv<1, false, false>(acc, tw, data, tid);   // follows a forward transform, whose cross-wave reads are fenced
+        ntt_inv<1, false>(acc, tw, data, tid);   // follows a forward transform, whose cross-wave reads are fenced
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const double v = (DEC ? (double)bi[k] + acc[0][k] : (double)bi[k] - acc[0][k]) + carry[k];

@@ -12,10 +12,12 @@ namespace fk {
 
 // out[0] = sum_r a_r * g_r,  out[1] = sum_r a_r * g_{r ^ 1}   (negacyclic, R terms, R even), raw doubles.
 // SINGLE: every transform runs on its own instead of two at a time, half a phase apart.
-template <bool SINGLE>
+// ROUNDED: the inverse transforms end with the path's rounding (nat_out<true>), i.e. they report to the round-off monitor.
+template <bool SINGLE, bool ROUNDED = false>
 __global__ __launch_bounds__(T) void k_selftest_convolve(const int32_t* __restrict__ a, const int32_t* __restrict__ g, double* __restrict__ out,
                                                          const double* __restrict__ tw_g, double ninv, int R) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    RoMonitor ro_mon(lds, tw_g, ROUNDED);
     double* tw = lds;
     double* data = lds + LDS_TW;
     const int tid = vt((int)threadIdx.x);
@@ -55,11 +57,11 @@ __global__ __launch_bounds__(T) void k_selftest_convolve(const int32_t* __restri
     if constexpr (SINGLE) {
         double* const d0[1] = {data};
         double* const d1[1] = {data + LDS_DATA};
-        fft_inv_skew<1, 1, false>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, d0, tid);
-        fft_inv_skew<1, 1, false>(*reinterpret_cast<double(*)[1][E]>(&acc[1]), tw, d1, tid);
+        fft_inv_skew<1, 1, ROUNDED>(*reinterpret_cast<double(*)[1][E]>(&acc[0]), tw, d0, tid);
+        fft_inv_skew<1, 1, ROUNDED>(*reinterpret_cast<double(*)[1][E]>(&acc[1]), tw, d1, tid);
     } else {
         double* const d[2] = {data, data + LDS_DATA};
-        fft_inv_skew<2, 1, false>(acc, tw, d, tid);
+        fft_inv_skew<2, 1, ROUNDED>(acc, tw, d, tid);
     }
 #pragma unroll
     for (int b = 0; b < 2; b++)
@@ -71,7 +73,17 @@ __global__ __launch_bounds__(T) void k_selftest_convolve(const int32_t* __restri
 
 extern "C" {
 
+namespace {
+int selftest_run(fheram_ctx* c, int n_terms, const int32_t* a, const int32_t* g, double* out, int singles, bool rounded, double scale);
+}
 int fheram_selftest_convolve(fheram_ctx* c, int n_terms, const int32_t* a, const int32_t* g, double* out, int singles) {
+    return selftest_run(c, n_terms, a, g, out, singles, false, 1.0);
+}
+int fheram_selftest_convolve_rounded(fheram_ctx* c, int n_terms, const int32_t* a, const int32_t* g, double* out, double operand_scale) {
+    return selftest_run(c, n_terms, a, g, out, 0, true, operand_scale);
+}
+namespace {
+int selftest_run(fheram_ctx* c, int n_terms, const int32_t* a, const int32_t* g, double* out, int singles, bool rounded, double scale) {
     if (!c || n_terms <= 0 || n_terms > 8 || (n_terms & 1) || !a || !g || !out) return fail(c, FHERAM_ERR_INVALID_ARG, "bad argument (n_terms: even, <= 8)");
     HIPCHK(c, hipSetDevice(c->device));
     int32_t* d = nullptr;
@@ -83,8 +95,10 @@ int fheram_selftest_convolve(fheram_ctx* c, int n_terms, const int32_t* a, const
     if (e == hipSuccess) e = hipMemcpy(d + (size_t)n_terms * fk::N, g, nb, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fk::k_selftest_convolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk::LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fk::k_selftest_convolve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk::LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fk::k_selftest_convolve<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fk::LDS_BYTES);
     if (e == hipSuccess) {
-        if (singles) hipLaunchKernelGGL(fk::k_selftest_convolve<true>, dim3(1), dim3(fk::T), fk::LDS_BYTES, c->stream, d, d + (size_t)n_terms * fk::N, dout, c->d_tw, c->ninv, n_terms);
+        if (rounded) hipLaunchKernelGGL((fk::k_selftest_convolve<false, true>), dim3(1), dim3(fk::T), fk::LDS_BYTES, c->stream, d, d + (size_t)n_terms * fk::N, dout, c->d_tw, c->ninv * scale, n_terms);
+        else if (singles) hipLaunchKernelGGL(fk::k_selftest_convolve<true>, dim3(1), dim3(fk::T), fk::LDS_BYTES, c->stream, d, d + (size_t)n_terms * fk::N, dout, c->d_tw, c->ninv, n_terms);
         else hipLaunchKernelGGL(fk::k_selftest_convolve<false>, dim3(1), dim3(fk::T), fk::LDS_BYTES, c->stream, d, d + (size_t)n_terms * fk::N, dout, c->d_tw, c->ninv, n_terms);
         e = hipStreamSynchronize(c->stream);
     }
@@ -92,7 +106,8 @@ int fheram_selftest_convolve(fheram_ctx* c, int n_terms, const int32_t* a, const
     hipFree(d);
     if (dout) hipFree(dout);
     if (e != hipSuccess) return fail(c, FHERAM_ERR_DEVICE, std::string("selftest: ") + hipGetErrorString(e));
-    return FHERAM_OK;
+    return rounded ? check_precision(c) : FHERAM_OK;
 }
+}  // namespace
 
 }  // extern "C"

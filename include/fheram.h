@@ -38,7 +38,9 @@ enum fheram_status {
     FHERAM_ERR_KEYS = 4,          /* missing key / auto_key.p() != -1: coordinate_prepared.rs:134 */
     FHERAM_ERR_UNSUPPORTED = 5,   /* parameter set the kernels are not built for             */
     FHERAM_ERR_RANGE = 6,         /* a limb is not normalised                                */
-    FHERAM_ERR_DEVICE = 7         /* HIP runtime error                                       */
+    FHERAM_ERR_DEVICE = 7,        /* HIP runtime error                                       */
+    FHERAM_ERR_PRECISION = 8      /* the FP64 round-off monitor saw |x - rint(x)| > 1/4 (no reference counterpart: Poulpy's FFT64
+                                     backend, examples/fhe-ram.rs:3-7, rounds unchecked)     */
 };
 
 /* Parameters (parameters.rs:11-21,147-152). */
@@ -114,6 +116,19 @@ int fheram_result_map(fheram_ctx* ctx, const int64_t** out);
 /* Block until every queued operation of ctx has finished. */
 int fheram_sync(fheram_ctx* ctx);
 
+/* ---- The exactness contract, checked.  The reference multiplies with Poulpy's FFT64 backend and rounds (examples/fhe-ram.rs:3-7);
+ * so does csrc/fft_dev.hpp: the rounded output of an inverse transform is the exact integer only while the accumulated FP64
+ * round-off stays below 1/2.  No a-priori bound below 1/2 is known for six accumulated terms of extreme limbs (measured worst
+ * case found by search 0.219: DESIGN.md §2), so every rounding on the path reports |x - rint(x)|, every coefficient, to a
+ * per-context monitor (fheram_config.monitor, on by default; 0.3 % of a step).
+ *   fheram_roundoff_max: waits for the context's streams; *max_out = the largest round-off seen since creation / the last reset;
+ *                        returns FHERAM_ERR_PRECISION if it exceeds 1/4 (max_out is still written).
+ *   Once a round-off above 1/4 was seen, every call that waits for the device (fheram_sync, the downloads of fheram_read /
+ *   fheram_read_prepare_write / fheram_result_map / fheram_ram_download, fheram_timer_end) returns FHERAM_ERR_PRECISION until
+ *   fheram_roundoff_reset.  No reference counterpart. */
+int fheram_roundoff_max(fheram_ctx* ctx, double* max_out);
+int fheram_roundoff_reset(fheram_ctx* ctx);
+
 /* ---- Row-sharded RAM across the GPUs of a node.  The reference is single
  * threaded and has no counterpart; the split follows its control flow: the rows of one residue class
  * mod n_shards form a complete sub-tree of the GLWEPacker (bit-reversed feed, ram.rs:425-444), so a
@@ -147,8 +162,11 @@ typedef struct fheram_config {
     int32_t graph;        /* 1: replay each op's launch sequence from a hipGraph */
     int32_t safe;         /* 1: no in-kernel hand-offs between workgroups, no gate wave: stays inside the HIP memory model */
     int32_t nco;          /* output columns per workgroup: 1, 2, or 0 = chosen per launch */
-    int32_t reserved;
+    int32_t monitor;      /* round-off monitor (fheram_roundoff_max): 1 (default) every rounding of an inverse transform reports its round-off; 0 nothing is reported or checked */
+    int32_t reserved;     /* must be 0 (a later version / size field): fheram_ctx_create_cfg refuses anything else */
 } fheram_config;
+/* ALWAYS start from fheram_config_default(): a zero-initialised struct is a valid configuration, but it selects every slow
+ * path (no chains, no fused launches, no memo) and switches the round-off monitor off. */
 void fheram_config_default(fheram_config* cfg);
 /* fheram_ctx_create_sharded with explicit switches (cfg == NULL: fheram_config_default) */
 int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_shards, const fheram_config* cfg, fheram_ctx** out);
@@ -230,6 +248,8 @@ int fheram_group_peer_info(const fheram_group* grp, int* direct, int n);
  * with an assert (wrong state, foreign address, ram.rs:393-396,404,472-475,555-558) are refused before anything is enqueued and
  * poison nothing. */
 int fheram_group_poisoned(const fheram_group* grp);
+/* the largest round-off over the shards' monitors (fheram_roundoff_max on every shard) */
+int fheram_group_roundoff_max(fheram_group* grp, double* max_out);
 
 /* ---- Poulpy-level operations reached from the path, exposed for
  * parity tests and micro-benchmarks.  Inputs/outputs are host buffers in the layouts above. */
@@ -365,6 +385,10 @@ int fheram_device_info(const fheram_ctx* ctx, char* name, size_t name_len, int* 
  * (singles != 0: every transform on its own instead of two at a time).  The caller compares with exact integer arithmetic
  * (tests/test_gpu_fft.py).  Not on the RAM path. */
 int fheram_selftest_convolve(fheram_ctx* ctx, int n_terms, const int32_t* a, const int32_t* g, double* out, int singles);
+/* The same products with the ROUNDING of the path (nat_out) and therefore through the round-off monitor: out = the rounded
+ * sums.  operand_scale multiplies the prepared operands (1.0: the path's arithmetic; 0.5 makes every odd sum a half-integer,
+ * which is how tests/test_gpu_fft.py drives the monitor over its limit and checks FHERAM_ERR_PRECISION). */
+int fheram_selftest_convolve_rounded(fheram_ctx* ctx, int n_terms, const int32_t* a, const int32_t* g, double* out, double operand_scale);
 
 #ifdef __cplusplus
 }

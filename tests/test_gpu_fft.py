@@ -50,14 +50,17 @@ def _patterns(rng, terms):
 
 
 @pytest.mark.parametrize("singles", [False, True])
-@pytest.mark.parametrize("terms", [2, 6])
+@pytest.mark.parametrize("terms", [2, 6, 8])
 def test_products_round_to_the_exact_integers(ram, terms, singles):
+    """6 terms = the path's maximum; 8 = what the entry point accepts: the bounds scale with the sums (8/6)"""
     rng = np.random.default_rng(7 + terms)
     for name, a, g, bound in _patterns(rng, terms):
+        if terms > 6:
+            bound *= terms / 6.0
         raw = ram.selftest_convolve(a, g, singles=singles)
         want0 = exact_negacyclic(a, g)
         want1 = exact_negacyclic(a, g[np.arange(terms) ^ 1])
-        assert np.abs(want0).max() < 2 ** 47
+        assert np.abs(want0).max() < 2 ** 47 * terms / 6
         err = max(np.abs(raw[0] - want0).max(), np.abs(raw[1] - want1).max())
         assert err <= bound, (name, terms, singles, err)
         assert np.array_equal(np.rint(raw[0]).astype(np.int64), want0), name
@@ -70,3 +73,58 @@ def test_pairs_and_singles_agree_bit_for_bit(ram):
     a = rng.integers(-(1 << 16), 1 << 16, (4, N))
     g = rng.integers(-(1 << 16), 1 << 16, (4, N))
     assert np.array_equal(ram.selftest_convolve(a, g, singles=False), ram.selftest_convolve(a, g, singles=True))
+
+
+# ---- the round-off monitor (fheram_roundoff_max): what turns a violated contract into an error -------------------------------------
+def test_monitor_sees_the_roundoff_of_the_rounded_path():
+    """the monitor's maximum after ROUNDED products = the raw round-off of the same products (every coefficient is reported)"""
+    pkg = load_package()
+    ram = pkg.Ram(pkg.Parameters(max_addr=4096, decomp_n=[3, 3, 3, 3], word_size=4))
+    assert ram.forms()["monitor"] == 1
+    assert ram.roundoff_max() == 0.0
+    const = np.full((6, N), -(1 << 16))
+    raw = ram.selftest_convolve(const, const)
+    want0 = exact_negacyclic(const, const)
+    err_raw = max(np.abs(raw[0] - want0).max(), np.abs(raw[1] - want0).max())
+    rounded = ram.selftest_convolve_rounded(const, const)
+    assert np.array_equal(rounded[0].astype(np.int64), want0)
+    ro = ram.roundoff_max()
+    assert ro == err_raw, (ro, err_raw)          # same instructions, same operands: the same doubles
+    assert 0.05 < ro <= 0.2
+    ram.roundoff_reset()
+    assert ram.roundoff_max() == 0.0
+
+
+def test_monitor_off_reports_nothing():
+    pkg = load_package()
+    rng = np.random.default_rng(3)
+    a, g = rng.integers(-(1 << 16), 1 << 16, (6, N)), rng.integers(-(1 << 16), 1 << 16, (6, N))
+    off = pkg.Ram(pkg.Parameters(max_addr=4096, decomp_n=[3, 3, 3, 3], word_size=4), config={"monitor": 0})
+    off.selftest_convolve_rounded(a, g)
+    assert off.roundoff_max() == 0.0
+    off.selftest_convolve_rounded(a[:2] * 0 + 1, g[:2] * 0 + 1, operand_scale=0.5)      # would be a PRECISION error with the monitor on
+    off.sync()
+
+
+def test_precision_error_is_raised_and_sticky():
+    """operands scaled by 1/2: every odd sum is a half-integer, |x - rint(x)| = 1/2 > 1/4 -> FHERAM_ERR_PRECISION, from the call
+    that saw it and from every later call that waits for the device, until the monitor is reset"""
+    pkg = load_package()
+    ram = pkg.Ram(pkg.Parameters(max_addr=4096, decomp_n=[3, 3, 3, 3], word_size=4))
+    one = np.zeros((2, N), dtype=np.int64)
+    one[0, 0] = 1                                  # a_0 = 1, a_1 = 0
+    g = one.copy()                                 # sum_r a_r * g_r = 1 (coefficient 0): halved by the operand scale it is 1/2
+    with pytest.raises(pkg.FheRamError) as e:
+        ram.selftest_convolve_rounded(one, g, operand_scale=0.5)
+    assert e.value.code == 8
+    with pytest.raises(pkg.FheRamError) as e:
+        ram.sync()
+    assert e.value.code == 8
+    assert 0.49 < ram.roundoff_max(check=False) <= 0.5
+    with pytest.raises(pkg.FheRamError):
+        ram.roundoff_max()
+    ram.roundoff_reset()
+    ram.sync()
+    assert ram.roundoff_max() == 0.0
+    ram.selftest_convolve_rounded(one, g)          # the path's own scaling: exact, no error
+    assert ram.roundoff_max() == 0.0
