@@ -56,6 +56,17 @@ def fp64_per_keyswitch(s_evk):
 
 FP64_PER_KS = fp64_per_keyswitch(4)
 FP64_PER_EP = 6 * FP64_FWD + 8 * FP64_INV + 48 * FP64_MAC     # external product: 6 forward, 8 inverse transforms, 48 polynomial MACs
+# ALGORITHMIC flops (what any FFT-based implementation of the same products needs, not this implementation's instruction stream):
+# 5 n log2 n per transform on n = 2048 complex points, 8 per complex multiply-accumulate
+ALG_FLOP_TRANSFORM = 5 * 2048 * 11
+ALG_FLOP_MAC = 8 * 2048
+ALG_FLOP_PER_EP = 14 * ALG_FLOP_TRANSFORM + 48 * ALG_FLOP_MAC
+
+
+def alg_flop_per_keyswitch(s_evk):
+    return (3 + 2 * s_evk) * ALG_FLOP_TRANSFORM + 6 * s_evk * ALG_FLOP_MAC
+
+
 # round 4's arithmetic (48-bit prime in FP64: 8 instructions per modular butterfly on 4096 points, 7 per MAC), for comparison only
 R04_FP64_PER_KS = 11 * 24576 * 8 + 24 * 4096 * 7
 R04_FP64_PER_EP = 14 * 24576 * 8 + 48 * 4096 * 7
@@ -101,7 +112,15 @@ def algorithmic_bytes(max_addr, ws, n_digits, atk_i64=ATK_I64):
     return read, rpw, write
 
 
-PMC_PROFILE = "profiles/r05_pmc_hbm_traffic.json"
+def _first_existing(*names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, n)):
+            return n
+    return names[0]
+
+
+PMC_PROFILE = _first_existing("profiles/r06_pmc_hbm_traffic.json", "profiles/r05_pmc_hbm_traffic.json")
+SQ_PROFILE = _first_existing("profiles/r06_pmc_sq_summary.txt", "profiles/r05_pmc_sq_summary.txt")
 
 
 def pmc_profile():
@@ -126,7 +145,7 @@ def pmc_traffic(kernel_prefix):
 
 def pmc_valu_busy(kernel_label):
     """VALU busy fraction of a kernel from the committed SQ-counter summary (None if absent)"""
-    path = os.path.join(ROOT, "profiles", "r05_pmc_sq_summary.txt")
+    path = os.path.join(ROOT, SQ_PROFILE)
     if not os.path.exists(path):
         return None
     import re
@@ -193,6 +212,41 @@ def cpu_baseline(max_addr, ws, inp, threads, crypto=None, sub_ram=None):
     ram.write(w, addr, keys)
     t3 = time.perf_counter()
     return (t1 - t0, t2 - t1, t3 - t2), {"read": r, "rpw": q, "rows_after_write": ram.store()}
+
+
+def readme_leg(pkg, ws, log_max_addr, device, steps, warmup):
+    """The README parameter block (README.md:17-27: K_PT = 9, K_EVK = 85, 5-limb trace keys) on a context of its own: the block
+    the reference's published 450 / 1200 ms were taken with (README.md:36).  Short: per-op HIP-event times over `steps` steps."""
+    crypto = {"k_glwe_pt": 9, "k_evk_trace": 85}
+    ram = pkg.Ram.new_from_ram_params(ws, [3, 3, 3, 3], 1 << log_max_addr, device=device, **crypto)
+    p = ram.params
+    inp = make_inputs(p, ws, 5, p.base2d().as_1d().size(), ram.local_rows(), 1234, 4321)
+    keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(inp["atk"]), inp["atk_inv"], inp["tsk"])
+    addr = pkg.Address(p, list(inp["addr"]))
+    ram.load_encrypted(inp["rows"])
+    ram.stage_words(inp["words"])
+    ops = (lambda: ram.read(addr, keys, download=False), lambda: ram.read_prepare_write(addr, keys, download=False), lambda: ram.write(None, addr, keys))
+    for _ in range(warmup):
+        for fn in ops:
+            fn()
+            ram.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for fn in ops:
+            fn()
+            ram.sync()
+    elapsed = time.perf_counter() - t0
+    ts = []
+    for _ in range(steps):
+        row = []
+        for fn in ops:
+            ram.timer_begin()
+            fn()
+            row.append(ram.timer_end())
+        ts.append(row)
+    r, q, w = np.array(ts).mean(axis=0)
+    return {"read_ms": float(r), "read_prepare_write_ms": float(q), "write_ms": float(w), "ms_per_step": elapsed * 1e3 / steps,
+            "ram_ops_s": 2 * steps / elapsed, "steps": steps, "roundoff_max": ram.roundoff_max()}
 
 
 def sha(a):
@@ -373,6 +427,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-boundary", action="store_true", help="skip the pass that includes the host hand-over")
+    ap.add_argument("--no-readme-leg", action="store_true", help="skip the short pass on the README parameter block (reference_published)")
     args = ap.parse_args()
 
     if args.mode == "group":
@@ -595,6 +650,7 @@ def main():
     out = {
         "metric": f"encrypted RAM read ops/s + write ops/s at 2^{args.log_max_addr} entries; achieved HBM GB/s vs peak",
         "value": raw_ops_per_s,
+        "value_incl_boundary": None,     # filled below: the same steps with the result handed to the host (what the reference's calls return)
         "unit": "RAM ops/s (1 read + 1 write[=rpw+write] per step)" + (
             f" of the ONE 2^{log_entries}-entry RAM sharded over the {world} GPUs (weak scaling: 2^{args.log_max_addr} entries per GPU; "
             f"value(N) / value(1) = T(1) / T(N) is the weak-scaling efficiency)" if weight > 1 else ""),
@@ -626,20 +682,34 @@ def main():
                                                "synchronisation at the end; `value` keeps one host round trip per op, as the reference's calls have"}),
         "algorithmic_GBs_per_op": {"read": a_read / read_ms / 1e6, "read_prepare_write": a_rpw / rpw_ms / 1e6,
                                    "write": a_write / write_ms / 1e6},
-        "reference_published": {"read_ms": 450, "write_ms": 1200, "hw": "i9-12900K single thread (README.md:36), 2^18 entries",
-                                "speedup_read": 450.0 / read_ms, "speedup_write": 1200.0 / write_ms,
-                                "speedup_rpw_plus_write": (450.0 + 1200.0) / (rpw_ms + write_ms),
-                                "same_parameter_block": bool(crypto),
-                                "note": ("measured on the README's own parameter block" if crypto else
-                                         "the published numbers were taken with the README block (5-limb trace keys; run --params readme for the "
-                                         "like-for-like ratio); these ratios are against the cheaper source constants")
-                                        + "; call for call as the example times them (examples/fhe-ram.rs:98-154); Ram::write here resumes from "
-                                          "what read_prepare_write kept, so speedup_rpw_plus_write (a read_prepare_write priced as a published "
-                                          "read) is the fairer write figure"},
+        "reference_published": None,     # filled below: the published numbers against THIS run's times on the published block
         "trace_tail": dict(tail, note="trace chains at the end of a read run as one launch with in-kernel hand-offs; `fallbacks` of them "
                                       "gave up (CUs not available side by side) and were redone by the fused launch behind them"),
         "device": ram.device_info(),
     }
+    # The reference's only published numbers (README.md:36: 450 ms read / 1200 ms write, i9-12900K single thread, 2^18 entries) were
+    # taken with the README parameter block (5-limb trace keys), not with the source constants `value` is measured on: the ratios
+    # are quoted for the block they belong to — this run's own times when it IS that block, else a short leg on that block.
+    pub = {"read_ms": 450, "write_ms": 1200, "hw": "i9-12900K single thread (README.md:36), 2^18 entries, README.md:17-27 parameter block"}
+    leg = None
+    if crypto:
+        leg = {"read_ms": float(read_ms), "read_prepare_write_ms": float(rpw_ms), "write_ms": float(write_ms), "ms_per_step": ms_per_step,
+               "ram_ops_s": raw_ops_per_s, "steps": args.steps}
+    elif mode == "single" and not args.no_readme_leg and args.log_max_addr == 18:
+        leg = readme_leg(pkg, ws, args.log_max_addr, local_rank, max(5, min(args.steps, 20)), 5)
+    if leg is not None:
+        pub.update({"measured_on_the_same_block": leg,
+                    "speedup_read": 450.0 / leg["read_ms"], "speedup_write": 1200.0 / leg["write_ms"],
+                    "speedup_rpw_plus_write": (450.0 + 1200.0) / (leg["read_prepare_write_ms"] + leg["write_ms"]),
+                    "note": "like for like: the README block on this GPU" + ("" if crypto else " (a short leg of this run on a context of its own; `value` stays the source constants)")
+                            + "; call for call as the example times them (examples/fhe-ram.rs:98-154); Ram::write here resumes from what "
+                              "read_prepare_write kept, so speedup_rpw_plus_write (a read_prepare_write priced as a published read) is the fairer write figure"})
+    else:
+        pub["note"] = "not measured in this run (the published numbers belong to the README block at 2^18: run --params readme)"
+    out["reference_published"] = pub
+    out["roundoff_max"] = {"value": ram.roundoff_max(), "limit": 0.375,
+                           "what": "largest |x - rint(x)| any rounding of an inverse transform has seen on the timed context (fheram_roundoff_max): the FFT64 "
+                                   "arithmetic is exact while it stays below 1/2; above 3/8 every call returns FHERAM_ERR_PRECISION"}
     out["mid_chain"] = dict(mid, note="dependent chains on 9..64 ciphertexts (MAX_ADDR 2^14..2^16) as one launch with in-kernel hand-offs (k_chain_mid); fallbacks = ciphertexts redone by the launch behind")
     if tail["fallbacks"] > 0 or mid["fallbacks"] > 0:
         out["trace_tail_degraded"] = True     # silent degradation made visible: some single-launch chains were redone by their fallback
@@ -647,7 +717,7 @@ def main():
     if boundary is not None:
         out["read_ms_incl_boundary"], out["rpw_ms_incl_boundary"], out["write_ms_incl_boundary"] = [float(x) for x in boundary]
         bstep = float(sum(boundary))
-        out["value_incl_boundary"] = 2e3 / bstep
+        out["value_incl_boundary"] = 2e3 / bstep     # (key created near the top of the line)
         out["ms_per_step_incl_boundary"] = bstep
         out["boundary_gap_frac"] = bstep / ms_per_step - 1.0
         out["boundary_note"] = ("what the reference's calls return (ram.rs:176,200: host ciphertexts): host wall clock per call through the ABI's "
@@ -664,13 +734,15 @@ def main():
         L0r = max(0, 12 - max(0, (-(-max_addr // N) - 1).bit_length()))
         # Every launch class that a step's GPU time splits into (disjoint: the nested event pairs are subtracted), with the FP64
         # work its launches carry (per ciphertext: products x FP64_PER_EP + key-switches x fp64_per_ks) and the kernel it is.
-        def entry(kernel, what, ms, launches, fp64, pmc=None, steps_per_launch=None):
+        def entry(kernel, what, ms, launches, fp64, pmc=None, steps_per_launch=None, alg=None):
             if not launches or ms <= 0:
                 return None
             t = fp64 / (ms * 1e-3) / 1e12
             e = {"kernel": kernel, "what": what, "launches": launches, "avg_launch_ms": ms / launches, "gpu_ms": ms,
                  "achieved_T_fp64_instr_s": t, "achieved": 2 * t, "peak": 2 * FP64_VALU_PEAK_TINSTR, "unit": "TFLOP/s", "bound": "valu_fp64",
-                 "frac": t / FP64_VALU_PEAK_TINSTR, "traffic": pmc_traffic(pmc) if pmc else None}
+                 "frac": t / FP64_VALU_PEAK_TINSTR,
+                 "frac_algorithmic": None if alg is None else alg / (ms * 1e-3) / 1e12 / (2 * FP64_VALU_PEAK_TINSTR),
+                 "traffic": pmc_traffic(pmc) if pmc else None}
             if steps_per_launch:
                 e["steps_per_launch"] = steps_per_launch
             return e
@@ -683,22 +755,27 @@ def main():
         rest_ep_ms = epc["ms"] - mde["ms"]
         rest_ep_blocks = epc["blocks"] - mde["blocks"]
         sk = s_evk
+        alg_ks = alg_flop_per_keyswitch(s_evk)
         table = [
             entry(f"k_read_chain<{sk},4>", f"a row's {d0} products of coordinate 0 + its {L0r} alone packer levels as ONE launch, one workgroup per row (ram.rs:429-435,502-514)",
-                  rc["ms"], rc["launches"], rc["blocks"] * (d0 * FP64_PER_EP + L0r * fp64_per_ks), f"fk::k_read_chain<{sk}, 4>", d0 + L0r),
+                  rc["ms"], rc["launches"], rc["blocks"] * (d0 * FP64_PER_EP + L0r * fp64_per_ks), f"fk::k_read_chain<{sk}, 4>", d0 + L0r,
+                  alg=rc["blocks"] * (d0 * ALG_FLOP_PER_EP + L0r * alg_ks)),
             entry(f"k_write_chain<{sk},4>", f"write_mid_step's 12 trace steps of ct_lo X^-row + normalize(ct_hi - trace(ct_hi) + .) + write_last_step's {d0} products as ONE launch (ram.rs:612-646)",
-                  wc["ms"], wc["launches"], wc["blocks"] * (d0 * FP64_PER_EP + 12 * fp64_per_ks), f"fk::k_write_chain<{sk}, 4>", d0 + 12),
+                  wc["ms"], wc["launches"], wc["blocks"] * (d0 * FP64_PER_EP + 12 * fp64_per_ks), f"fk::k_write_chain<{sk}, 4>", d0 + 12,
+                  alg=wc["blocks"] * (d0 * ALG_FLOP_PER_EP + 12 * alg_ks)),
             entry(f"k_keyswitch_chain<3,{sk},3,{forms.get('chain_y', 3)}>", "pure trace chains, one workgroup per ciphertext (at 2^18: trace(ct_hi) steps 6..11 on the write's side stream, ram.rs:616)",
                   pure_ms, pc["launches"], pc["blocks"] * fp64_per_ks, f"fk::k_keyswitch_chain<3, {sk}, 3, {forms.get('chain_y', 3)}>",
-                  (pc["blocks"] / pc["launches"] / max(1.0, classes["keyswitch_fused"]["blocks"] / max(1, classes["keyswitch_fused"]["launches"]))) if pc["launches"] else None),
+                  (pc["blocks"] / pc["launches"] / max(1.0, classes["keyswitch_fused"]["blocks"] / max(1, classes["keyswitch_fused"]["launches"]))) if pc["launches"] else None,
+                  alg=pc["blocks"] * alg_ks),
             entry(f"k_trace_tail<3,{sk},3>", "GLWE::trace on the word_size results at the end of a read: 12 dependent steps as one launch with in-kernel hand-offs (ram.rs:457,540)",
-                  tl["ms"], tl["launches"], tl["blocks"] * fp64_per_ks, f"fk::k_trace_tail<3, {sk}, 3>"),
+                  tl["ms"], tl["launches"], tl["blocks"] * fp64_per_ks, f"fk::k_trace_tail<3, {sk}, 3>", alg=tl["blocks"] * alg_ks),
             entry("k_chain_mid<...>", "dependent chains on 9..64 ciphertexts as one launch with in-kernel hand-offs (MAX_ADDR 2^13..2^16)",
-                  md["ms"] + mde["ms"], md["launches"] + mde["launches"], md["blocks"] * fp64_per_ks + mde["blocks"] * FP64_PER_EP),
+                  md["ms"] + mde["ms"], md["launches"] + mde["launches"], md["blocks"] * fp64_per_ks + mde["blocks"] * FP64_PER_EP,
+                  alg=md["blocks"] * alg_ks + mde["blocks"] * ALG_FLOP_PER_EP),
             entry("k_pair_z / k_keyswitch / k_keyswitch_fine + _norm", "the pair levels of the packing tree and the other key-switch launches of the dependent end of an op (4..128 ciphertexts per launch)",
-                  rest_ks_ms, ksc["launches"] - pc["launches"] - tl["launches"] - md["launches"], rest_ks_blocks * fp64_per_ks),
+                  rest_ks_ms, ksc["launches"] - pc["launches"] - tl["launches"] - md["launches"], rest_ks_blocks * fp64_per_ks, alg=rest_ks_blocks * alg_ks),
             entry("k_ext_product_fine + _norm / k_ext_product", "coordinate 1's products on word_size ciphertexts",
-                  rest_ep_ms, epc["launches"] - mde["launches"], rest_ep_blocks * FP64_PER_EP),
+                  rest_ep_ms, epc["launches"] - mde["launches"], rest_ep_blocks * FP64_PER_EP, alg=rest_ep_blocks * ALG_FLOP_PER_EP),
             entry("k_prepare", "CoordinatePrepared::prepare: forward transforms of the address digits", classes["prepare"]["ms"], classes["prepare"]["launches"],
                   classes["prepare"]["blocks"] * FP64_FWD),
             entry("elementwise (k_sub_add_norm, k_rotate, k_copy)", "write_first_step, rotations, copies", classes["elementwise"]["ms"], classes["elementwise"]["launches"], 0),
@@ -710,9 +787,8 @@ def main():
         table.sort(key=lambda e: -e["gpu_ms"])
         note = ("frac prices the implementation's OWN FP64 instruction stream (6 / 8 instructions per complex butterfly of the FFT64 transforms, 4 per "
                 "complex MAC, 1 per rounding) against the 39.3 T instr/s issue peak: utilisation of the FP64 pipe, not a bound on the "
-                "algorithm.  Round 5 replaced round 4's modular transforms (8 instructions per butterfly on twice as many points, 7 per "
-                "MAC: 2.47x the FP64 instructions per key-switch, 2.66x per product) — the same launch at round 4's count is "
-                "frac_at_round4_instruction_count, for comparison with the r04 profiles only.  What now shares the step with the FP64 "
+                "algorithm; frac_algorithmic prices the same launch in ALGORITHMIC flops (5 n log2 n per transform on n = 2048 complex points, 8 per "
+                "complex multiply-accumulate) against the 78.6 TFLOP/s vector FP64 peak.  What shares the step with the FP64 "
                 "pipe: the swap rounds and address arithmetic of the transforms (VALU, not FP64), two 32 KB LDS exchanges per transform, and "
                 "the prepared operands streamed from the XCD's L2 under the inverse transforms (32 KB per polynomial MAC; at 2^18 the product runs at "
                 "~60 % of the L2's share per CU): see `pipes`.")
@@ -729,7 +805,10 @@ def main():
                 ratio = R04_FP64_PER_KS / FP64_PER_KS if s_evk == 4 else None
                 n_ep, n_ks = 0, 1
             dom["note"] = note
-            dom["frac_at_round4_instruction_count"] = None if ratio is None else dom["frac"] * ratio
+            # (comparison aid for the r04 profiles only — NOT a roofline figure, hence outside the `roofline` block)
+            out["history"] = {"frac_at_round4_instruction_count": None if ratio is None else dom["frac"] * ratio,
+                              "what": "the dominant launch of this run priced with ROUND 4's instruction count (modular transforms: 2.47x the FP64 instructions per key-switch, "
+                                      "2.66x per product): only for comparing with profiles/r04_*"}
             dom["fp64_instr_per_keyswitch"] = fp64_per_ks
             dom["fp64_instr_per_product"] = FP64_PER_EP
             dom["traffic_source"] = PMC_PROFILE + " (HBM-side bytes per launch of this kernel: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE scaled by the factor calibrated on a known-bytes stream, tools/fetch_calib.hip; FETCH_SIZE counts Infinity-Cache hits)"
@@ -742,7 +821,7 @@ def main():
             opnd_bytes = n_mac * 32768
             dom["pipes"] = {"what": "per workgroup (= per CU: one ciphertext each) and launch, from the kernel's structure; rates against the CU's own peaks at the clock the stamps show (2.19 GHz)",
                             "valu_busy_frac_pmc": pmc_valu_busy(dom["kernel"]),
-                            "valu_busy_source": "profiles/r05_pmc_sq_summary.txt: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of this kernel x 2 waves per SIMD (a separate rocprofv3 --pmc pass of this command): the share of time the vector ALU issues ANY instruction (FP64, swap rounds, address and digit arithmetic)",
+                            "valu_busy_source": SQ_PROFILE + ": SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of this kernel x 2 waves per SIMD (a separate rocprofv3 --pmc pass of this command): the share of time the vector ALU issues ANY instruction (FP64, swap rounds, address and digit arithmetic)",
                             "transforms": n_tr, "polynomial_macs": n_mac,
                             "fp64_busy_frac": dom["frac"],
                             "lds_bytes": lds_bytes, "lds_GBs_per_cu": lds_bytes / t_launch / 1e9, "lds_peak_GBs_per_cu": "~85 B/clk stores, 256 B/clk loads (MI355X_MICROARCH.md LDS table): 186 / 560",
@@ -803,6 +882,7 @@ def main():
                                                   "fp64_instr_per_step": fp_step,
                                                   "achieved_T_fp64_instr_s": fp_step / (ms_per_step * 1e-3) / 1e12,
                                                   "frac": fp_step / (ms_per_step * 1e-3) / 1e12 / FP64_VALU_PEAK_TINSTR,
+                                                  "frac_algorithmic": (ep_ref * ALG_FLOP_PER_EP + ks_exec * alg_ks) / (ms_per_step * 1e-3) / 1e12 / (2 * FP64_VALU_PEAK_TINSTR),
                                                   "note": "GGSW prepares and inversions (< 2 % of the work) not counted"}}
         out["kernel_classes"] = classes
         out["kernel_timing_pass"] = {"what": "separate pass of the same K steps with per-launch HIP events on the launch stream "

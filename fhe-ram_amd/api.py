@@ -43,7 +43,7 @@ class _CParams(C.Structure):
 
 
 _CONFIG_FIELDS = ("limb_split", "fine_split", "memo", "pre_inv", "tail", "tail_test", "mid", "mid_test", "chain", "chain_y", "pair_z",
-                  "fuse", "graph", "safe", "nco", "monitor", "reserved")
+                  "fuse", "graph", "safe", "nco", "tail_ep", "monitor", "reserved")
 
 
 class _CConfig(C.Structure):
@@ -814,7 +814,7 @@ class Ram:
     # -- the exactness contract of the FFT64 arithmetic, checked (fheram_roundoff_max)
     def roundoff_max(self, check: bool = True) -> float:
         """largest |x - rint(x)| any monitored rounding of an inverse transform has seen on this context since its creation / the
-        last reset; raises FheRamError(8, PRECISION) above 1/4 unless check is False"""
+        last reset; raises FheRamError(8, PRECISION) above 3/8 unless check is False"""
         m = C.c_double()
         rc = library().fheram_roundoff_max(self._h, C.byref(m))
         if rc != 0 and (check or rc != 8):
@@ -1050,7 +1050,7 @@ class GroupRam:
         return bool(library().fheram_group_poisoned(self._h))
 
     def roundoff_max(self) -> float:
-        """the largest round-off over the shards' monitors (fheram_group_roundoff_max); raises PRECISION above 1/4"""
+        """the largest round-off over the shards' monitors (fheram_group_roundoff_max); raises PRECISION above 3/8"""
         m = C.c_double()
         self._chk(library().fheram_group_roundoff_max(self._h, C.byref(m)))
         return float(m.value)

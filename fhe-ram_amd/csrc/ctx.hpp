@@ -100,6 +100,7 @@ struct fheram_ctx {
     //        FHERAM_TAIL=0: one launch pair per step as before;  FHERAM_TAIL=2 / 3: test hooks, the launch gives up two steps before its end
     //        and the fused fallback launch behind it does the work.
     int tail = 1;
+    int tail_ep = 1;                   // coordinate 1's products (two digits or more) run inside that launch, in front of the trace steps (FHERAM_TAIL_EP=0: launches of their own)
     int tail_test = 0;                 // FHERAM_TAIL=2 / 3: every launch gives up late; 3 keeps the watch below active
     unsigned tail_seq = 0;
     int tail_xoff = 0;                 // first XCD of this context's groups (0 or 4, alternating over contexts and processes)
@@ -132,10 +133,11 @@ struct fheram_ctx {
     //              with another address, or after new keys, computes them itself.  FHERAM_PRE_INV=0: always.
     int pair_z = 1;                // FHERAM_PAIR_Z=0: the column-split packer combine with the limb-by-limb normalisation (k_keyswitch<KS_PAIR,...,1>) instead of k_pair_z
     int fuse = 1;                  // FHERAM_FUSE=0: a row's product chain and trace chain as two launches (and the write's elementwise step as a third) instead of k_read_chain / k_write_chain
+    bool wide = false;             // the launch being enqueued can never meet the gate wave (Ram::read, Ram::write: only read_prepare_write parks one): the chain kernels' 256-register variants
     int safe = 0;                  // FHERAM_SAFE=1: no in-kernel hand-offs between workgroups, no gate wave (fheram.hip)
     //  Round-off monitor (fft_dev.hpp mon_note / RoMonitor): every rounding of an inverse transform reports |x - rint(x)|; the
     //  context's maximum lives behind its twiddle table (d_tw[N]), and a pinned host word is set once it passed MON_LIMIT.
-    int monitor = 1;               // 0: nothing is reported or checked; 1 (default): every coefficient of every rounding
+    int monitor = 1;               // 0: nothing is reported or checked; 1 (default): one coefficient per thread and transform; 2 (`safe`): every coefficient
     unsigned* h_ro_flag = nullptr; // pinned, device-visible: 1 = a round-off above MON_LIMIT was seen (sticky until fheram_roundoff_reset)
     int pre_inv = 1;
     uint64_t inv_id[2] = {0, 0};
@@ -203,7 +205,7 @@ int fail(fheram_ctx* c, int code, const std::string& msg) {
 // Called wherever the host has just waited for the device: the sticky flag of the round-off monitor turns into a status.
 int check_precision(fheram_ctx* c) {
     if (c->h_ro_flag && __atomic_load_n(c->h_ro_flag, __ATOMIC_RELAXED))
-        return fail(c, FHERAM_ERR_PRECISION, "FP64 round-off of an inverse transform exceeded 1/4 (fheram_roundoff_max): the rounded integers are no longer trustworthy");
+        return fail(c, FHERAM_ERR_PRECISION, "FP64 round-off of an inverse transform exceeded 3/8 (fheram_roundoff_max): the rounded integers are no longer trustworthy");
     return FHERAM_OK;
 }
 #define HIPCHK(c, call)                                                                     \

@@ -47,12 +47,13 @@ constexpr int LDS_MON = T;       // doubles: one slot per thread for the round-o
 constexpr int MON_OFF = LDS_TW + BMAX * LDS_DATA;
 constexpr size_t LDS_BYTES = (size_t)(LDS_TW + BMAX * LDS_DATA + LDS_MON) * sizeof(double);
 // The twiddle table in global memory is N doubles followed by the monitor's two words (one table per context):
-//   [0]      slot of W[0], which the recursion never reads: its FIRST DWORD is the monitor mode (0: nothing is reported, 1: on);
+//   [0]      slot of W[0], which the recursion never reads: its FIRST DWORD is the monitor mode (0: nothing is reported, 1: one
+//            coefficient per thread and transform, 2: every coefficient);
 //            [1] stays 0.0 (its upper dword is the split barrier's counter in LDS)
 //   [N]      max |x - rint(x)| over every monitored rounding so far, as the bits of a non-negative double (unsigned max)
 //   [N + 1]  device-visible address of a pinned host word that is set to 1 once a round-off above MON_LIMIT was seen
 constexpr int TW_GLOBAL = N + 2;
-constexpr double MON_LIMIT = 0.25;
+constexpr double MON_LIMIT = 0.375;   // halfway between the largest round-off any search has produced (0.25: tools/fft_search.hip) and failure (0.5)
 
 typedef double d2 __attribute__((ext_vector_type(2)));   // (re, im)
 
@@ -285,19 +286,34 @@ __device__ __forceinline__ void nat_in(d2 (&y)[4], const double (&a)[E]) {
 }
 // ---- round-off monitor ------------------------------------------------------------------------------------------------------------
 // The rounded output of an inverse transform is the exact integer only while the accumulated FP64 round-off stays below 1/2.
-// Every rounding on the path reports max |x - rint(x)| over the thread's eight coefficients into the thread's own LDS slot
-// (ds_max on the bits of a non-negative double: no return value, nothing waits for it, no branch: ~16 FP64 instructions
-// beside the ~180 of the transform); RoMonitor, constructed at the top of every kernel that rounds, folds the slots into the
-// context's maximum when the kernel ends — one comparison per wave against the value the kernel started from (a scalar load at
-// kernel start), one global atomic only from a wave that raises it.  Measured: 0.3 % of a step (profiles/r06_experiments.txt).
+// Every rounding on the path reports |x - rint(x)| into the thread's own LDS slot (ds_max on the bits of a non-negative
+// double: no return value, nothing waits for it); RoMonitor, constructed at the top of every kernel that rounds, folds the
+// slots into the context's maximum when the kernel ends — one comparison per wave against the value the kernel started from (a
+// scalar load at kernel start), one global atomic only from a wave that raises it.
+// Mode (first dword of the table's slot 0, copied to LDS with the table; read at the START of an inverse transform, with its
+// first twiddles, so that the rounding itself waits for nothing): 0 nothing is reported, 1 ONE coefficient per thread and
+// transform — which of the thread's eight is a compile-time choice of the call site (SEL), so the sites of a kernel cover
+// different classes tid + 512 k —, 2 all eight (fheram_config.monitor = 2, what `safe` selects: +2.9 % of a step, the
+// sampled form +0.x %: profiles/r06_experiments.txt).
 #ifndef FK_MONITOR
 #define FK_MONITOR 1     // 0: compiled out (A/B measurements only)
 #endif
-__device__ __forceinline__ void mon_note(const double* tw_lds, int tid, const d2 (&y)[4], const double (&a)[E]) {
+__device__ __forceinline__ unsigned mon_mode(const double* tw_lds) {
 #if FK_MONITOR
-    double m = __builtin_fmax(__builtin_fabs(y[0].x - a[0]), __builtin_fabs(y[0].y - a[4]));
+    return __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(tw_lds)[0]);
+#else
+    return 0u;
+#endif
+}
+template <int SEL>
+__device__ __forceinline__ void mon_note(const double* tw_lds, int tid, const d2 (&y)[4], const double (&a)[E], unsigned mode) {
+#if FK_MONITOR
+    static_assert(SEL >= 0 && SEL < E, "one of the thread's eight coefficients");
+    double m = __builtin_fabs((SEL < 4 ? y[SEL & 3].x : y[SEL & 3].y) - a[SEL]);
+    if (mode > 1u) {   // (wave uniform)
 #pragma unroll
-    for (int k = 1; k < 4; k++) m = __builtin_fmax(m, __builtin_fmax(__builtin_fabs(y[k].x - a[k]), __builtin_fabs(y[k].y - a[k + 4])));
+        for (int k = 0; k < 4; k++) m = __builtin_fmax(m, __builtin_fmax(__builtin_fabs(y[k].x - a[k]), __builtin_fabs(y[k].y - a[k + 4])));
+    }
     unsigned long long* slot = reinterpret_cast<unsigned long long*>(const_cast<double*>(tw_lds) + MON_OFF + tid);
     __hip_atomic_fetch_max(slot, (unsigned long long)__double_as_longlong(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #endif
@@ -340,14 +356,14 @@ struct RoMonitor {
 #endif
     }
 };
-template <bool ROUND = true>
-__device__ __forceinline__ void nat_out(const d2 (&y)[4], double (&a)[E], const double* tw_lds, int tid) {
+template <bool ROUND = true, int SEL = 0>
+__device__ __forceinline__ void nat_out(const d2 (&y)[4], double (&a)[E], const double* tw_lds, int tid, unsigned mode) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if constexpr (ROUND) { a[k] = __builtin_rint(y[k].x); a[k + 4] = __builtin_rint(y[k].y); }
         else { a[k] = y[k].x; a[k + 4] = y[k].y; }   // (round-off measurements only)
     }
-    if constexpr (ROUND) mon_note(tw_lds, tid, y, a);
+    if constexpr (ROUND) mon_note<SEL>(tw_lds, tid, y, a, mode);
 }
 __device__ __forceinline__ void dom_in(d2 (&y)[4], const double (&a)[E]) {
 #pragma unroll
@@ -404,6 +420,7 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
     const XAddr xa = xaddr(tid);
     d2 y[B][4];
     Tw7 t2, t1; Tw5 t0;
+    const unsigned mon = ROUND ? mon_mode(tw_) : 0u;
     tw_p2(t2, tw, xa);
 #pragma unroll
     for (int b = 0; b < B; b++) dom_in(y[b], x[b]);
@@ -427,7 +444,10 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
 #pragma unroll
     for (int b = 0; b < B; b++) x0a_r(y[b], reinterpret_cast<d2*>(d[b]), xa);
 #pragma unroll
-    for (int b = 0; b < B; b++) { i_pass3(y[b], t0); nat_out<ROUND>(y[b], x[b], tw_, tid); }
+    for (int b = 0; b < B; b++) {
+        i_pass3(y[b], t0);
+        if (b == 0) nat_out<ROUND, 0>(y[b], x[b], tw_, tid, mon); else if (b == 1) nat_out<ROUND, 3>(y[b], x[b], tw_, tid, mon); else nat_out<ROUND, 6>(y[b], x[b], tw_, tid, mon);
+    }
     if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
 }
 
@@ -438,13 +458,14 @@ __device__ __forceinline__ void fft_inv_skew(double (&x)[B][E], const double* tw
 // taken): the operand stream of a chain step — 0.75 to 1.5 MB per step through the CU's ~57 B/clk load path — then runs under the
 // transforms instead of beside them (tools/fft_bench.hip, k_stream: a transform pair with 192 KB requested in front of it takes
 // 3.19 us against 3.04 without the loads and 1.60 for the loads alone).
-template <int FENCE, bool ROUND = true, class Hook>
+template <int FENCE, bool ROUND = true, int MSEL = 5, class Hook>
 __device__ __forceinline__ void fft_inv1_hooked(double (&x)[1][E], const double* tw_, double* d0, int tid, Hook&& hook) {
     const d2* tw = reinterpret_cast<const d2*>(tw_);
     d2* buf = reinterpret_cast<d2*>(d0);
     const XAddr xa = xaddr(tid);
     d2 y[4];
     Tw7 t2, t1; Tw5 t0;
+    const unsigned mon = ROUND ? mon_mode(tw_) : 0u;
     tw_p2(t2, tw, xa);
     dom_in(y, x[0]);
     if constexpr (FENCE == 1) lds_barrier();
@@ -471,17 +492,18 @@ __device__ __forceinline__ void fft_inv1_hooked(double (&x)[1][E], const double*
     __builtin_amdgcn_sched_barrier(0);
     hook(std::integral_constant<int, 3>{});
     __builtin_amdgcn_sched_barrier(0);
-    nat_out<ROUND>(y, x[0], tw_, tid);
+    nat_out<ROUND, MSEL>(y, x[0], tw_, tid, mon);
 }
 
 // ---- TWO inverse transforms half a phase apart with work of the caller's between their phases (six places) ------------------------------
-template <int FENCE, class Hook>
+template <int FENCE, int MSEL = 1, class Hook>
 __device__ __forceinline__ void fft_inv2_hooked(double (&x)[2][E], const double* tw_, double* d0, double* d1, int tid, Hook&& hook) {
     const d2* tw = reinterpret_cast<const d2*>(tw_);
     d2* const buf[2] = {reinterpret_cast<d2*>(d0), reinterpret_cast<d2*>(d1)};
     const XAddr xa = xaddr(tid);
     d2 y[2][4];
     Tw7 t2, t1; Tw5 t0;
+    const unsigned mon = mon_mode(tw_);
     tw_p2(t2, tw, xa);
     dom_in(y[0], x[0]); dom_in(y[1], x[1]);
     if constexpr (FENCE == 1) lds_barrier();
@@ -505,9 +527,9 @@ __device__ __forceinline__ void fft_inv2_hooked(double (&x)[2][E], const double*
     x0a_r(y[0], buf[0], xa);
     x0a_r(y[1], buf[1], xa);
     FK_HOOK(4);
-    i_pass3(y[0], t0); nat_out<true>(y[0], x[0], tw_, tid);
+    i_pass3(y[0], t0); nat_out<true, MSEL>(y[0], x[0], tw_, tid, mon);
     FK_HOOK(5);
-    i_pass3(y[1], t0); nat_out<true>(y[1], x[1], tw_, tid);
+    i_pass3(y[1], t0); nat_out<true, (MSEL + 3) % E>(y[1], x[1], tw_, tid, mon);
 #undef FK_HOOK
     if constexpr (FENCE == 2) sb_arrive_free(sb_addr(tw_));
 }

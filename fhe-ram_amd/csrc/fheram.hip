@@ -26,7 +26,7 @@ void fheram_config_default(fheram_config* cfg) {
     if (!cfg) return;
     fheram_config d{};
     d.limb_split = 1; d.fine_split = 1; d.memo = 1; d.pre_inv = 1; d.tail = 1; d.tail_test = 0; d.mid = 2; d.mid_test = 0;
-    d.chain = 1; d.chain_y = 3; d.pair_z = 1; d.fuse = 1; d.graph = 0; d.safe = 0; d.nco = 0; d.monitor = 1; d.reserved = 0;
+    d.chain = 1; d.chain_y = 3; d.pair_z = 1; d.fuse = 1; d.graph = 0; d.safe = 0; d.nco = 0; d.tail_ep = 1; d.monitor = 1; d.reserved = 0;
     auto env = [](const char* n) { const char* v = getenv(n); return (v && v[0]) ? v[0] : '\0'; };
     if (env("FHERAM_LIMB_SPLIT") == '0') d.limb_split = 0;
     if (env("FHERAM_FINE_SPLIT") == '0') d.fine_split = 0;
@@ -46,8 +46,9 @@ void fheram_config_default(fheram_config* cfg) {
     if (env("FHERAM_SAFE") == '1') d.safe = 1;
     const char nc = env("FHERAM_NCO");
     d.nco = nc == '2' ? 2 : (nc == '1' ? 1 : 0);
+    if (env("FHERAM_TAIL_EP") == '0') d.tail_ep = 0;
     const char mo = env("FHERAM_MONITOR");
-    if (mo == '0') d.monitor = 0;
+    if (mo == '0') d.monitor = 0; else if (mo == '2') d.monitor = 2;
     *cfg = d;
 }
 
@@ -149,6 +150,7 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
         static std::atomic<int> serial{0};
         c->tail_xoff = ((serial++ + (int)getpid()) & 1) * (TAIL_GROUPS / 2);
         c->tail_test = cfg.tail_test < 0 ? 0 : (cfg.tail_test > 2 ? 2 : cfg.tail_test);
+        c->tail_ep = cfg.tail_ep ? 1 : 0;
         c->mid = cfg.mid < 0 ? 0 : (cfg.mid > 2 ? 2 : cfg.mid);   // 1: the <= 16 ciphertext split only
         c->mid_test = cfg.mid_test ? 1 : 0;
         c->chain = cfg.chain ? 1 : 0;
@@ -165,7 +167,9 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
         // Same results (tests/test_gpu_golden.py); priced in profiles/r05_bench_safe.json.
         c->safe = cfg.safe ? 1 : 0;
         if (c->safe) { c->tail = 0; c->tail_test = 0; c->mid = 0; c->mid_test = 0; if (c->pre_inv == 1) c->pre_inv = 2; }
-        c->monitor = cfg.monitor ? 1 : 0;   // round-off monitor: on by default (every coefficient of every rounding)
+        // round-off monitor: one coefficient per thread and transform by default, every coefficient under `safe`
+        c->monitor = cfg.monitor < 0 ? 0 : (cfg.monitor > 2 ? 2 : cfg.monitor);
+        if (c->safe && c->monitor == 1) c->monitor = 2;
         c->nco = cfg.nco == 2 ? 2 : (cfg.nco == 1 ? 1 : 0);
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
@@ -181,6 +185,8 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
     LDSATTR((&k_ext_product_chain_r<4>));
     LDSATTR((&k_pair_z<4>)); LDSATTR((&k_pair_z<5>));
     LDSATTR((&k_read_chain<4, 4>)); LDSATTR((&k_read_chain<5, 4>)); LDSATTR((&k_write_chain<4, 4>)); LDSATTR((&k_write_chain<5, 4>));
+    LDSATTR((&k_read_chain_w<4, 4>)); LDSATTR((&k_read_chain_w<5, 4>));
+    LDSATTR((&k_keyswitch_chain_w<3, 4, 3, 3>)); LDSATTR((&k_keyswitch_chain_w<3, 5, 3, 3>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3>));
     LDSATTR((&k_keyswitch_chain<3, 4, 3, 3>));
     LDSATTR((&k_keyswitch_chain<3, 5, 3, 3>));
@@ -306,7 +312,7 @@ int fheram_ctx_config(const fheram_ctx* c, fheram_config* out) {
     fheram_config d{};
     d.limb_split = c->limb_split; d.fine_split = c->fine_split; d.memo = c->memo; d.pre_inv = c->pre_inv; d.tail = c->tail; d.tail_test = c->tail_test;
     d.mid = c->mid; d.mid_test = c->mid_test; d.chain = c->chain; d.chain_y = c->chain_y; d.pair_z = c->pair_z; d.fuse = c->fuse;
-    d.graph = c->use_graph; d.safe = c->safe; d.nco = c->nco; d.monitor = c->monitor;
+    d.graph = c->use_graph; d.safe = c->safe; d.nco = c->nco; d.monitor = c->monitor; d.tail_ep = c->tail_ep;
     *out = d;
     return FHERAM_OK;
 }

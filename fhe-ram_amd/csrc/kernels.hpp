@@ -328,6 +328,11 @@ constexpr int BF = FK_BF, BI = FK_BI;
 #ifndef FK_CHAIN_VGPRS
 #define FK_CHAIN_VGPRS 120   // the attribute counts in units of two on gfx90a+ (unified VGPR + AGPR file): 120 -> 240 registers: two waves leave 32 registers of a SIMD for a small third one
 #endif
+// ... and the same kernels with the whole register file (128 -> 256 registers), for the launches that can never meet the gate wave: it is
+// parked by read_prepare_write only, so Ram::read and Ram::write run the wide variants (k_read_chain<4,4>: 89 -> 19 spilled registers,
+// k_keyswitch_chain<3,4,3,3>: 29 -> 13; +2.6 % RAM ops/s, +3.6 % on the README block: profiles/r06_experiments.txt)
+// (the attribute wants a literal: the wide variants are second kernels around the same body: k_read_chain_w, k_keyswitch_chain_w)
+#define FK_WIDE_VGPRS 128
 static_assert(BF <= BMAX && BI <= BMAX, "LDS holds BMAX exchange buffers");
 
 // forward transform of S polynomials, BF at a time
@@ -1346,6 +1351,9 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         auto unit = [&](auto nb_tag, auto p_tag, auto nh_tag, auto swap_tag, auto j_tag) {
             constexpr int NB = decltype(nb_tag)::value, P = decltype(p_tag)::value, NH = decltype(nh_tag)::value, J = decltype(j_tag)::value;
             constexpr bool SWAP = decltype(swap_tag)::value;
+            int tid_u = tid;
+            asm volatile("" : "+v"(tid_u));   // per-unit copy (see k_ext_product_chain): six unrolled units would otherwise share — and keep alive — every address derived from it
+            __builtin_assume(tid_u >= 0 && tid_u < T);
             double acc[NB][E];
             if constexpr (NB == 2) {
 #pragma unroll
@@ -1361,15 +1369,15 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
                     mac_regs(accn[sl / SX], xh[pp % SX], w[pp % KW]);
                     pin_regs(accn[sl / SX]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (pp + KW < NTOT) load_ops(w[pp % KW], kop(pp + KW), tid);
+                    if constexpr (pp + KW < NTOT) load_ops(w[pp % KW], kop(pp + KW), tid_u);
                 }
             };
             if constexpr (NB == 2) {
-                fft_inv2_hooked<2>(acc, tw, data, data + LDS_DATA, tid, hook);
+                fft_inv2_hooked<2>(acc, tw, data, data + LDS_DATA, tid_u, hook);
                 fold_limb<SK>(od, ec, acc[0], J);
                 fold_limb<SK>(od, ec, acc[1], J - 1);
             } else {
-                fft_inv1_hooked<2>(acc, tw, data, tid, hook);
+                fft_inv1_hooked<2>(acc, tw, data, tid_u, hook);
                 fold_limb<SK>(od, ec, acc[0], J);
             }
         };
@@ -1391,6 +1399,7 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
         // the step's stream of 2 * SK * SX operand polynomials.  Two accumulator pairs: the one being transformed, the one being summed.
         auto batch = [&](auto hn_tag, auto hnn_tag, const int j) {
             constexpr bool HN = decltype(hn_tag)::value, HNN = decltype(hnn_tag)::value;
+            const int tid_u = tid;   // (a per-batch copy the optimiser cannot see through, as in the five-limb units above, removes two thirds of this kernel's spill code and is 0.7 % slower: profiles/r06_experiments.txt)
             double acc[2][E];
 #pragma unroll
             for (int b = 0; b < 2; b++)
@@ -1404,12 +1413,12 @@ __device__ __forceinline__ void ks_trace_l(const KsArgs& ka, double* lds, bool l
                     mac_regs(accn[q / SX], xh[q % SX], w[q % KW]);
                     pin_regs(accn[q / SX]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (q + KW < NQ) load_ops(w[q % KW], kopnd(nco, nj, q + KW), tid);
-                    else if constexpr (HNN) load_ops(w[q % KW], kopnd(nnco, nnj, q + KW - NQ), tid);
+                    if constexpr (q + KW < NQ) load_ops(w[q % KW], kopnd(nco, nj, q + KW), tid_u);
+                    else if constexpr (HNN) load_ops(w[q % KW], kopnd(nnco, nnj, q + KW - NQ), tid_u);
                 }
             };
             YSTAMP(8 + (ci * SK + (SK - 1 - j)) * 4);
-            fft_inv2_hooked<2>(acc, tw, data, data + LDS_DATA, tid, hook);
+            fft_inv2_hooked<2>(acc, tw, data, data + LDS_DATA, tid_u, hook);
             YSTAMP(9 + (ci * SK + (SK - 1 - j)) * 4);
             if constexpr (SK == 4) { fold_limb4<SK>(od, acc[0], j); fold_limb4<SK>(od, acc[1], j - 1); }
             else { fold_limb<SK>(od, ec, acc[0], j); fold_limb<SK>(od, ec, acc[1], j - 1); }
@@ -1571,6 +1580,7 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
         // differ: they are peeled, so that the steady-state body has no branch.
         auto unit = [&](auto hn_tag, auto hnn_tag, const int j) {
             constexpr bool HN = decltype(hn_tag)::value, HNN = decltype(hnn_tag)::value;
+            const int tid_u = tid;
             double acc[1][E];
 #pragma unroll
             for (int k = 0; k < E; k++) { acc[0][k] = accn[k]; accn[k] = 0.0; }
@@ -1582,8 +1592,8 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
                     mac_regs(accn, q < SA ? x0[q % SA] : x1[q % SA], w[q % W]);
                     pin_regs(accn);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (q + W < NQ) load_ops(w[q % W], opnd(nco, nj, q + W), tid);
-                    else if constexpr (HNN) load_ops(w[q % W], opnd(nnco, nnj, q + W - NQ), tid);
+                    if constexpr (q + W < NQ) load_ops(w[q % W], opnd(nco, nj, q + W), tid_u);
+                    else if constexpr (HNN) load_ops(w[q % W], opnd(nnco, nnj, q + W - NQ), tid_u);
                 }
             };
             auto hook = [&](auto stag) {
@@ -1591,13 +1601,13 @@ __device__ __forceinline__ void ep_step_r(GlweRef a, GlweRef res, const double* 
                 step(std::integral_constant<int, sl>{});   // one product per place: evenly spaced requests
             };
             YSTAMP(8 + (co * SG + (SG - 1 - j)) * 4);
-            fft_inv1_hooked<2>(acc, tw, data, tid, hook);   // one exchange buffer, fenced by the free counter; buffer 1 holds V (below)
+            fft_inv1_hooked<2>(acc, tw, data, tid_u, hook);   // one exchange buffer, fenced by the free counter; buffer 1 holds V (below)
             YSTAMP(9 + (co * SG + (SG - 1 - j)) * 4);
             __builtin_amdgcn_sched_barrier(0);
             step(std::integral_constant<int, 4>{});
             __builtin_amdgcn_sched_barrier(0);
             {   // V of this column lives in this thread's own slots of exchange buffer 1 between the folds (16 registers fewer across the transform)
-                double2* odp = reinterpret_cast<double2*>(data + LDS_DATA) + tid;
+                double2* odp = reinterpret_cast<double2*>(data + LDS_DATA) + tid_u;
                 if (j != SG - 1) {
 #pragma unroll
                     for (int kk = 0; kk < E / 2; kk++) { const double2 v = odp[kk * T]; od[2 * kk] = v.x; od[2 * kk + 1] = v.y; }
@@ -1701,52 +1711,6 @@ struct KsChainArgs {
 // file, and ANY other wave resident on the CU — the one-wave gate launch that read_prepare_write parks on the side stream is
 // enough — keeps the workgroup off that CU: a 256-workgroup launch on 256 CUs then runs in two rounds (+0.24 ms per
 // read_prepare_write, measured when the Y-form kernel first compiled to 250).  Capped so that a small wave still fits.
-template <int SX, int SK, int SO, int YF = 0>   // YF: 0 int32 limbs between the steps (ks_run); 3 the intermediates as Y = ceil(A/2) with the closed-form normalisation, handed over through LDS and registers (ks_trace_l)
-__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_keyswitch_chain(KsChainArgs ca) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    RoMonitor ro_mon(lds, ca.base.tw);
-    if (ca.pred) {
-        if (__hip_atomic_load(ca.pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.pred_seq) return;
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-            const unsigned taken = atomicAdd(const_cast<unsigned*>(ca.pred) + 1, 1u) + 1u;   // fallbacks taken (fheram_tail_stats)
-            if (ca.host_count) __hip_atomic_store(ca.host_count, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    if (ca.done) {
-        if (__hip_atomic_load(ca.done + (blockIdx.y * gridDim.x + blockIdx.x) * 32 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.done_seq) return;
-        if (threadIdx.x == 0) {
-            const unsigned taken = atomicAdd(ca.done + MID_GROUPS_MAX * 32 + 1, 1u) + 1u;   // ciphertexts redone (fheram_mid_stats)
-            if (ca.host_count) __hip_atomic_store(ca.host_count, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    KsArgs ka = ca.base;
-    [[maybe_unused]] double vcarry[E];   // YF = 3: the body column's Y on its way from one step to the next
-#pragma unroll
-    for (int k = 0; k < E; k++) vcarry[k] = 0.0;
-#pragma unroll 1
-    for (int i = 0; i < ca.n; i++) {
-        ka.out = ca.buf[i & 1];
-        ka.b = ka.a;
-        ka.key = ca.key[i];
-        ka.ginv = ca.ginv[i];
-        int tid = vt((int)threadIdx.x);
-        asm volatile("" : "+v"(tid));   // see k_ext_product_chain
-        __builtin_assume(tid >= 0 && tid < T);
-        if constexpr (YF == 3) {
-            static_assert(SX == 3 && SO == 3, "the Y form is written for 3-limb ciphertexts");
-            if (i == 0) ks_trace_l<SK, false, 1>(ka, lds, true, tid, vcarry);
-            else if (i + 1 < ca.n) ks_trace_l<SK, true, 1>(ka, lds, false, tid, vcarry, YSTAMP_STEP(i));
-            else ks_trace_l<SK, true, 0>(ka, lds, false, tid, vcarry);
-        } else {
-            ks_run<KS_TRACE, SX, SK, SO, 2, 0>(ka, lds, i == 0, tid);
-        }
-        if constexpr (YF != 3) __syncthreads();   // the step's stores have completed (vmcnt 0) and its LDS traffic is over (YF = 3: nothing passes through global memory)
-        ka.a = ka.out;
-        ka.rot_mul = 0;
-        ka.rot_base = 0;
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // k_pair_z (round 4): the packer combine (GLWEPacker, ram.rs:435,514; KS_PAIR of ks_run) split by output column, in the closed
 // form of ks_trace_z.  With A(v) = v_0 2^34 + v_1 2^17 + v_2 the integer a coefficient's limbs stand for and a' = rot(a, -t):
@@ -1901,42 +1865,26 @@ struct RowChainArgs {
     GlweRef hi, trhi;      // k_write_chain: the rows (ct_hi) and trace(ct_hi)
     int store_ep = 0;      // k_read_chain: the products' result is also stored (in-place products of read_prepare_write)
 };
-template <int SK, int SG>
-__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_read_chain(RowChainArgs ra) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    RoMonitor ro_mon(lds, ra.ep.tw);
-    double vc[E];
-#pragma unroll
-    for (int k = 0; k < E; k++) vc[k] = 0.0;
-    {
-        GlweRef in = ra.ep.src;
-#pragma unroll 1
-        for (int i = 0; i < ra.ep.n; i++) {      // n >= 2
-            const GlweRef out = ra.ep.buf[i & 1];
-            int tid = vt((int)threadIdx.x);
-            asm volatile("" : "+v"(tid));   // see k_ext_product_chain
-            __builtin_assume(tid >= 0 && tid < T);
-            if (i == 0) ep_step_r<SG, 0, 1>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, true, tid, vc);
-            else if (i + 1 < ra.ep.n) ep_step_r<SG, 1, 1>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, false, tid, vc);
-            else ep_step_r<SG, 1, 3>(in, out, ra.ep.ggsw[i], ra.ep.tw, lds, false, tid, vc, false, ra.store_ep != 0);
-            in = out;
-        }
-    }
-    KsArgs ka = ra.ks.base;
-#pragma unroll 1
-    for (int i = 0; i < ra.ks.n; i++) {          // n >= 1: every step takes its input from LDS and registers
-        ka.out = ra.ks.buf[i & 1];
-        ka.key = ra.ks.key[i];
-        ka.ginv = ra.ks.ginv[i];
-        int tid = vt((int)threadIdx.x);
-        asm volatile("" : "+v"(tid));
-        __builtin_assume(tid >= 0 && tid < T);
-        if (i + 1 < ra.ks.n) ks_trace_l<SK, true, 1>(ka, lds, false, tid, vc);
-        else ks_trace_l<SK, true, 0>(ka, lds, false, tid, vc);
-    }
-}
-template <int SK, int SG>
-__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_CHAIN_VGPRS))) void k_write_chain(RowChainArgs ra) {
+// (defined in chain_kernels.inc, which is included twice: k_keyswitch_chain / k_read_chain capped at FK_CHAIN_VGPRS registers for the launches that may
+// meet the gate wave, k_keyswitch_chain_w / k_read_chain_w with the whole register file for those that cannot — the attribute wants a literal,
+// and a shared body function would take the kernel's argument struct by reference, i.e. copy it to scratch)
+#define FK_KS_CHAIN_NAME k_keyswitch_chain
+#define FK_READ_CHAIN_NAME k_read_chain
+#define FK_VG FK_CHAIN_VGPRS
+#include "chain_kernels.inc"
+#undef FK_KS_CHAIN_NAME
+#undef FK_READ_CHAIN_NAME
+#undef FK_VG
+#define FK_KS_CHAIN_NAME k_keyswitch_chain_w
+#define FK_READ_CHAIN_NAME k_read_chain_w
+#define FK_VG FK_WIDE_VGPRS
+#include "chain_kernels.inc"
+#undef FK_KS_CHAIN_NAME
+#undef FK_READ_CHAIN_NAME
+#undef FK_VG
+
+template <int SK, int SG>   // (only ever launched by Ram::write: never beside the gate wave)
+__global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_WIDE_VGPRS))) void k_write_chain(RowChainArgs ra) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     RoMonitor ro_mon(lds, ra.ep.tw);
     double vc[E];   // (written by the first step before anything reads it)
@@ -2010,7 +1958,14 @@ struct TailArgs {
     int n, n_ct, gx;
     int xoff;                        // group g sits on the blocks with (b + 8 - xoff) % 8 == g: contexts that share a GPU start on different XCDs
     int give_up_at;                  // test hook: member 5 of group 0 gives up at this step (-1: never)
+    // round 6: the external products of coordinate 1 (ram.rs:454 / 525-527) in front of the trace chain, in the same launch: steps
+    // 0 .. n_ep-1 are products (fine split: member (co, j, r) of the first 24 transforms digit r of both columns, multiplies with its two
+    // operand polynomials and transforms back once; the normalisation phase is the products' own), steps n_ep .. n_ep+n-1 the trace
+    int n_ep = 0;
+    const double* ggsw[4];           // prepared digits of the coordinate
+    GlweRef ep_out;                  // where the last product's result goes = the trace chain's source (read_prepare_write: tree[0], ram.rs:526); not src, not buf[]
 };
+constexpr int TAIL_EP_MAX = 4;
 __device__ __forceinline__ int xcc_id() {
     int v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -2070,6 +2025,8 @@ template <int SX, int SK, int SO>
 __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int G = 2 * SK * SX;
+    constexpr int SG = 4, GE = 2 * SG * SX;        // a product: 4 output limbs per column, 24 active members
+    static_assert(GE <= G && SX == 3 && SO == 3, "the products' members are a subset of the trace steps'");
     const int g = ((int)blockIdx.x + TAIL_GROUPS - ta.xoff) % TAIL_GROUPS, m = (int)blockIdx.x / TAIL_GROUPS;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)   // the last block: every block of the launch has been placed (k_tail_gate)
         __hip_atomic_store(ta.sync + TAIL_GROUPS * 32 + 2, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2083,29 +2040,76 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
     unsigned* ctr = ta.sync + g * 32;
     unsigned* abortp = ta.sync + TAIL_GROUPS * 32;
     const int r = m % SX, zz = m / SX;
-    const int j = SK - 1 - zz % SK, co = zz / SK;
+    const int j = SK - 1 - zz % SK, co = zz / SK;                 // this member in a trace step
+    const int je = SG - 1 - zz % SG, coe = zz / SG;               // ... and in a product (m < GE)
+    const bool ep_member = m < GE;
     const long ct = (long)(g / ta.gx);
     const long cx = (long)(g % ta.gx);
     double* const big0 = ta.big + (long)g * BIG_STRIDE * SX;   // + step parity * TAIL_GROUPS * BIG_STRIDE * SX (see the normalisation phase)
-    OpRegs kop;
-    load_ops(kop, ta.key[0] + (long)((r * SK + j) * 2 + co) * N, tid);
+    const int n_ep = ta.n_ep, n_all = ta.n_ep + ta.n;
+    OpRegs kop, kop1;                 // the operand(s) of the coming step: a trace key polynomial, or the two GGSW polynomials of a product
+    if (n_ep > 0) {
+        if (ep_member) {
+            load_ops(kop, ta.ggsw[0] + (long)(((2 * r) * SG + je) * 2 + coe) * N, tid);
+            load_ops(kop1, ta.ggsw[0] + (long)(((2 * r + 1) * SG + je) * 2 + coe) * N, tid);
+        }
+    } else {
+        load_ops(kop, ta.key[0] + (long)((r * SK + j) * 2 + co) * N, tid);
+    }
     if (tid == 0) {
         __hip_atomic_fetch_or(ctr + 2, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // performed before this workgroup's first arrival is counted
     }
     load_twiddles(tw, ta.tw, tid);
     unsigned epoch = 0;
+    // step s_ writes: a product the ping-pong buffers (the last one ep_out), trace step t = s_ - n_ep buf[t & 1]
+    auto out_of = [&](int s_) -> GlweRef { return s_ < n_ep ? (s_ == n_ep - 1 ? ta.ep_out : ta.buf[s_ & 1]) : ta.buf[(s_ - n_ep) & 1]; };
 #pragma unroll 1
-    for (int s = 0; s < ta.n; s++) {
-        const GlweRef rin = (s == 0) ? ta.src : ta.buf[(s - 1) & 1];
-        const GlweRef rout = ta.buf[s & 1];
+    for (int s = 0; s < n_all; s++) {
+        const GlweRef rin = (s == 0) ? ta.src : out_of(s - 1);
+        const GlweRef rout = out_of(s);
         const int32_t* ap = rin.p + ct * rin.sy + cx * rin.sx;
         int32_t* op = rout.p + ct * rout.sy + cx * rout.sx;
-        const int ginv = ta.ginv[s];
-        const bool stepped = (s > 0);          // the input already is rsh1(a)
-        const bool last = (s + 1 == ta.n);
+        const bool is_ep = s < n_ep;
+        const int t = s - n_ep;                // trace step index (is_ep: negative)
+        const int ginv = is_ep ? 1 : ta.ginv[t];
+        const bool stepped = (t > 0);          // the input already is rsh1(a): written by the previous TRACE step of this launch
+        const bool fresh = (s == 0);           // the input was written by an earlier launch: ordinary loads
+        const bool last = (s + 1 == n_all);
         double* const bigg = big0 + (long)(s & 1) * TAIL_GROUPS * BIG_STRIDE * SX;
         TSTAMP(0);
+        if (is_ep) {
+            // ---- fine phase of a product: partial[co][j][r] = INTT(NTT(a.col0 limb r) . G[2r][j][co] + NTT(a.col1 limb r) . G[2r+1][j][co])
+            if (ep_member) {
+                double x[2][E];
+                if (fresh) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+                        for (int k = 0; k < E; k++) x[c2][k] = (double)gload_i32(ap + glwe_off(r, c2), (unsigned)(tid + T * k) * 4u);
+                } else {
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+                        for (int k = 0; k < E; k++) x[c2][k] = (double)ld_l2(ap + glwe_off(r, c2) + tid + T * k);
+                }
+                ntt_fwd<2>(x, tw, data, tid);
+                double acc[1][E];
+#pragma unroll
+                for (int k = 0; k < E; k++) acc[0][k] = 0.0;
+                mac_regs(acc[0], x[0], kop);
+                mac_regs(acc[0], x[1], kop1);
+                if (s + 1 < n_ep) {
+                    load_ops(kop, ta.ggsw[s + 1] + (long)(((2 * r) * SG + je) * 2 + coe) * N, tid);
+                    load_ops(kop1, ta.ggsw[s + 1] + (long)(((2 * r + 1) * SG + je) * 2 + coe) * N, tid);
+                }
+                ntt_inv<1, false>(acc, tw, data, tid);
+                double* bgp = bigg + (long)((coe * SG + je) * SX + r) * N;
+#pragma unroll
+                for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
+            }
+            if (s + 1 == n_ep && !last) load_ops(kop, ta.key[0] + (long)((r * SK + j) * 2 + co) * N, tid);   // the first trace step's operand (every member)
+        } else {
         // ---- fine phase: x = rsh1(a); partial[co][j][r] = INTT(NTT(phi_g(x.mask limb r)) . K[r][j][co]) (+ phi_g(x.body limb j))
         // staging: thread t brings coefficients 8t .. 8t+7 (natural order) of the limb polynomials it needs
         if (stepped) {
@@ -2115,15 +2119,22 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
 #pragma unroll
             for (int k = 0; k < E; k++) mstage[E * tid + k] = v[k];
         } else {
-            // the source was written by an earlier launch: ordinary (16-byte) loads
+            // the source: written by an earlier launch (ordinary 16-byte loads) or by the last product of this one (past the L1)
             int rm[SX][E];
+            if (fresh) {
 #pragma unroll
-            for (int q = 0; q < SX; q++)
+                for (int q = 0; q < SX; q++)
 #pragma unroll
-                for (int h = 0; h < E / 4; h++) {
-                    const int4 v4 = *reinterpret_cast<const int4*>(ap + glwe_off(q, 1) + E * tid + 4 * h);
-                    rm[q][4 * h] = v4.x; rm[q][4 * h + 1] = v4.y; rm[q][4 * h + 2] = v4.z; rm[q][4 * h + 3] = v4.w;
-                }
+                    for (int h = 0; h < E / 4; h++) {
+                        const int4 v4 = *reinterpret_cast<const int4*>(ap + glwe_off(q, 1) + E * tid + 4 * h);
+                        rm[q][4 * h] = v4.x; rm[q][4 * h + 1] = v4.y; rm[q][4 * h + 2] = v4.z; rm[q][4 * h + 3] = v4.w;
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < SX; q++)
+#pragma unroll
+                    for (int h = 0; h < E / 2; h++) ld_l2_pair(ap + glwe_off(q, 1) + E * tid + 2 * h, rm[q][2 * h], rm[q][2 * h + 1]);
+            }
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 int xi[SX], xm[SX];
@@ -2151,13 +2162,14 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
 #pragma unroll
         for (int k = 0; k < E; k++) acc[0][k] = 0.0;
         mac_regs(acc[0], x[0], kop);
-        if (!last) load_ops(kop, ta.key[s + 1] + (long)((r * SK + j) * 2 + co) * N, tid);   // arrives during the rest of the step
+        if (!last) load_ops(kop, ta.key[t + 1] + (long)((r * SK + j) * 2 + co) * N, tid);   // arrives during the rest of the step
         ntt_inv<1, false>(acc, tw, data, tid);
         TSTAMP(3);
         {
             double* bgp = bigg + (long)((co * SK + j) * SX + r) * N;
 #pragma unroll
             for (int k = 0; k < E; k++) bgp[tid + T * k] = acc[0][k];
+        }
         }
         if (ta.give_up_at == s && g == 0 && m == 5) {
             if (tid == 0) __hip_atomic_store(abortp, ta.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2166,12 +2178,12 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
         TSTAMP(4);
         if (!tail_barrier(ctr, abortp, ta.seq, (++epoch) * G, flag, s == 0, tid)) break;
         TSTAMP(5);
-        // ---- normalisation phase: one thread per (column, coefficient); same arithmetic as k_keyswitch_norm<KS_TRACE>.
+        // ---- normalisation phase: one thread per (column, coefficient); same arithmetic as k_keyswitch_norm<KS_TRACE> / k_ext_product_fine_norm.
         // Every member takes an equal share of each column (CH consecutive coefficients: the phase is as long as its busiest
-        // member's L2 reads; with T per member a third of the members had none).  The next fine phase needs the mask column
-        // only: the members announce themselves when their share of it is stored and do the body column under the hand-off's
+        // member's L2 reads; with T per member a third of the members had none).  The next fine phase of a TRACE step needs the mask
+        // column only: the members announce themselves when their share of it is stored and do the body column under the hand-off's
         // latency (nobody reads it before the next normalisation phase; the partials are double buffered by step parity for
-        // that, see k_chain_mid).
+        // that, see k_chain_mid).  A product's next fine phase reads both columns.
         constexpr int CH = (N + G - 1) / G;
         static_assert(CH <= T, "one coefficient per thread and column");
         auto norm_share = [&](const int nco) {
@@ -2222,6 +2234,34 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
                 for (int q = 0; q < SO; q++) op[glwe_off(q, nco) + i] = y[q];
             }
         };
+        // a product's: the sums over the three digits' partials, the limb walk, the normalised limbs as they are (they ARE the next product's digits)
+        auto norm_share_ep = [&](const int nco) {
+            const int i = m * CH + tid;
+            if (tid < CH && i < N) {
+                const double* bgp = bigg + (long)nco * SG * SX * N + i;
+                double v_[SG];
+#pragma unroll
+                for (int q = 0; q < SG; q++) {
+                    v_[q] = ld_l2(bgp + (long)(q * SX) * N);
+#pragma unroll
+                    for (int w = 1; w < SX; w++) v_[q] += ld_l2(bgp + (long)(q * SX + w) * N);   // exact: integers below 2^47
+                }
+                double carry = 0.0;
+#pragma unroll
+                for (int q = SG - 1; q >= 0; q--) {
+                    const double v = v_[q] + carry;
+                    const double cy = carry_of(v);
+                    carry = cy;
+                    if (q < SO) op[glwe_off(q, nco) + i] = (int)digit_of(v, cy);
+                }
+            }
+        };
+        if (is_ep) {
+            norm_share_ep(1);
+            norm_share_ep(0);
+            TSTAMP(6);
+            if (!last) { if (!tail_barrier(ctr, abortp, ta.seq, (++epoch) * G, flag, false, tid)) break; }
+        } else {
         norm_share(1);
         if (last) {
             norm_share(0);
@@ -2232,6 +2272,7 @@ __global__ __launch_bounds__(T, T / 256) void k_trace_tail(TailArgs ta) {
             TSTAMP(6);
             ++epoch;
             if (!tail_wait(ctr, abortp, ta.seq, epoch * G, flag, tid)) break;
+        }
         }
         TSTAMP(7);
     }

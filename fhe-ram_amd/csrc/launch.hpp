@@ -251,10 +251,12 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
     for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
     const int yf = n >= 2 ? c->chain_y : 0;   // intermediates handed over as Y = ceil(A/2) through LDS and registers (ks_trace_l); 0: int32 limbs (ks_run)
     if (c->s_evk == 5) {
-        if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf && c->wide) hipLaunchKernelGGL((k_keyswitch_chain_w<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        else if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     } else {
-        if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf && c->wide) hipLaunchKernelGGL((k_keyswitch_chain_w<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        else if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }
 }
@@ -284,8 +286,13 @@ void launch_read_chain(fheram_ctx* c, GlweRef src, const GlweRef* ep_store, Glwe
     ra.ks.base = ks_args(c, dst, dst, dst, trace_key(c, 0), c->gal[0]);
     ra.ks.buf[0] = ra.ks.buf[1] = dst;                            // only the last step stores
     ra.hi = dst; ra.trhi = dst;
-    if (c->s_evk == 5) hipLaunchKernelGGL((k_read_chain<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
-    else hipLaunchKernelGGL((k_read_chain<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+    if (c->s_evk == 5) {
+        if (c->wide) hipLaunchKernelGGL((k_read_chain_w<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+        else hipLaunchKernelGGL((k_read_chain<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+    } else {
+        if (c->wide) hipLaunchKernelGGL((k_read_chain_w<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+        else hipLaunchKernelGGL((k_read_chain<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+    }
 }
 // write: trace steps 0 .. n_tr-1 of ct_lo * X^-row (src, read rotated), data <- normalize(data - trhi + that), d products in place
 void launch_write_chain(fheram_ctx* c, GlweRef src, int rot_mul, int rot_base, GlweRef data, GlweRef trhi, const double* prep, int d, int n_tr, int gx, int gy) {
@@ -308,11 +315,17 @@ bool use_tail(const fheram_ctx* c, int n, int gx, int gy) {
            c->cus >= TAIL_GROUPS * 32 &&     // the whole chip (8 XCDs x 32 CUs): a partition could not hold the groups side by side
            !(c->use_graph && !c->profile);   // a captured launch would replay its generation number
 }
-void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy) {
+// prep != nullptr (round 6): the d external products with the prepared digits at `prep` run in front of the trace chain in the SAME launch
+// (coordinate 1's products, ram.rs:454 / 525-527): src -> products -> ep_out -> trace -> b[(n - 1) & 1]; store_ep: the caller needs ep_out
+// afterwards (read_prepare_write's tree[0]).  The fallback launch is then the fused row chain (k_read_chain), predicated likewise.
+void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int start, int n, int gx, int gy,
+                       const double* prep = nullptr, int d = 0, GlweRef ep_out = GlweRef{nullptr, 0, 0}, bool store_ep = false) {
     ProfScope ps(c, "keyswitch", (uint64_t)gx * gy, n);
     ProfScope pt(c, "keyswitch_tail_launch", (uint64_t)gx * gy * n, 1);
     TailArgs ta;
     ta.src = src; ta.buf[0] = b[0]; ta.buf[1] = b[1]; ta.tw = c->d_tw; ta.big = big_of(c); ta.sync = c->d_tail_sync;
+    ta.n_ep = prep ? d : 0; ta.ep_out = ep_out;
+    for (int i = 0; i < TAIL_EP_MAX; i++) ta.ggsw[i] = (prep && i < d) ? prep + (size_t)i * fheram_ctx::GGSW : nullptr;
     if (++c->tail_seq == 0) ++c->tail_seq;
     c->tail_launches++;
     if (c->tail_test != 1 && c->tail_launches - c->tail_launch_mark >= 64) {
@@ -321,18 +334,29 @@ void launch_trace_tail(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int st
         c->tail_fb_mark = fb;
         c->tail_launch_mark = c->tail_launches;
     }
-    ta.seq = c->tail_seq; ta.n = n; ta.n_ct = gx * gy; ta.gx = gx; ta.xoff = c->tail_xoff; ta.give_up_at = c->tail_test ? n - 2 : -1;   // late: every buffer but the source has been overwritten by then
+    ta.seq = c->tail_seq; ta.n = n; ta.n_ct = gx * gy; ta.gx = gx; ta.xoff = c->tail_xoff; ta.give_up_at = c->tail_test ? ta.n_ep + n - 2 : -1;   // late: every buffer but the source has been overwritten by then
     KsChainArgs ca;
     ca.base = ks_args(c, src, src, b[0], trace_key(c, start), c->gal[start], 0, 0, 0);
     ca.buf[0] = b[0]; ca.buf[1] = b[1]; ca.n = n;
     ca.pred = c->d_tail_sync + TAIL_GROUPS * 32; ca.pred_seq = ta.seq; ca.host_count = c->h_tail_fb;
     for (int i = 0; i < n; i++) { ta.key[i] = ca.key[i] = trace_key(c, start + i); ta.ginv[i] = ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
+    RowChainArgs ra;   // (the fallback of the products + trace form)
+    if (ta.n_ep) {
+        fill_row_chain(c, ra, prep, d, start, n);
+        ra.ep.src = src; ra.ep.buf[0] = ra.ep.buf[1] = ep_out; ra.store_ep = store_ep ? 1 : 0;
+        ra.ks.base = ks_args(c, b[(n - 1) & 1], b[(n - 1) & 1], b[(n - 1) & 1], trace_key(c, start), c->gal[start]);
+        ra.ks.buf[0] = ra.ks.buf[1] = b[(n - 1) & 1];      // only the last step stores
+        ra.hi = ra.trhi = b[(n - 1) & 1];
+        ra.ks.pred = ca.pred; ra.ks.pred_seq = ca.pred_seq; ra.ks.host_count = ca.host_count;
+    }
     if (c->s_evk == 5) {
         hipLaunchKernelGGL((k_trace_tail<3, 5, 3>), dim3(TAIL_GROUPS * 2 * 5 * 3), dim3(T), LDS_BYTES, c->cur, ta);
-        hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (ta.n_ep) hipLaunchKernelGGL((k_read_chain<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+        else hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     } else {
         hipLaunchKernelGGL((k_trace_tail<3, 4, 3>), dim3(TAIL_GROUPS * 2 * 4 * 3), dim3(T), LDS_BYTES, c->cur, ta);
-        hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (ta.n_ep) hipLaunchKernelGGL((k_read_chain<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+        else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }
 }
 // GLWE::trace(start, end): step i = rsh(1) then a += phi_{g_i}(KS(a)).

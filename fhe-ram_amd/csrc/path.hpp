@@ -61,6 +61,7 @@ int check_common(fheram_ctx* c, const fheram_addr* addr) {
 // inside the shard.  The packed GLWE of every sub-RAM is left where the last launch wrote it (*packed_out,
 // indexed by sub-RAM); to_part also copies it into d_part (the buffer a sharded RAM exchanges).
 int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweRef* packed_out, bool to_part) {
+    c->wide = !prepare_write;   // read_prepare_write parks the gate wave beside its launches (read_top): its chain kernels keep a wave slot free
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     const int ws = c->ws;
@@ -112,10 +113,15 @@ int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweR
 // coordinate-1 products and the final trace.  Result left in d_res.  Every step is out of place, so
 // nothing has to be copied between them.
 int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t* gathered, GlweRef pk) {
+    c->wide = !prepare_write;
     const long G = (long)fheram_ctx::GLWE;
     const int ws = c->ws;
     GlweRef tmp = ref(c->d_tmp, G, 0), tree = ref(c->d_tree, G, 0);
     GlweRef last = pk;
+    // coordinate 1's products inside the trace chain's launch (k_trace_tail's product steps): from two digits on (the fallback is the fused row chain)
+    const int d1q = c->n2 == 2 ? (int)c->base2d[1].size() : 0;
+    const bool fuse_ep = c->n2 == 2 && c->tail_ep && d1q >= 2 && d1q <= TAIL_EP_MAX && use_tail(c, LOGN, 1, ws);
+    GlweRef ep_out = prepare_write ? tree : ref(c->d_tmp2, G, 0);
     if (c->n2 == 2) {
         if (gathered) {
             const int kG = ilog2_ceil((size_t)c->n_shards);
@@ -127,7 +133,9 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
         if (!c->prep1_ready) coordinate_prepare(c, addr, 1);
         c->prep1_ready = false;
         const int d1 = (int)c->base2d[1].size();
-        if (prepare_write) {
+        if (fuse_ep) {
+            last = ep_out;                                                            // (enqueued below, with the trace chain)
+        } else if (prepare_write) {
             ep_chain(c, pk, tree, tmp, prep_of(c, 1), d1, 1, ws);                         // ram.rs:525-527 + 502-504 (i = 1): tree[0] <- rotated packed row
             last = tree;                                                              // ram.rs:535 (res <- tree[0])
         } else {
@@ -149,7 +157,13 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
     c->memo_top = prepare_write && c->memo;
     c->d_last_res = c->memo_top ? c->d_trtop : c->d_res;
     const uint64_t tl0 = c->tail_launches;
-    trace_steps(c, last, ref(c->d_last_res, G, 0), tmp, 0, LOGN, 1, ws);              // ram.rs:457 / 540
+    GlweRef tb[2];
+    if (fuse_ep && chain_bufs(LOGN, last, ref(c->d_last_res, G, 0), tmp, tb))          // ram.rs:454 / 525-527 + 457 / 540 as ONE launch
+        launch_trace_tail(c, pk, tb, 0, LOGN, 1, ws, prep_of(c, 1), d1q, ep_out, prepare_write);
+    else {
+        if (fuse_ep) ep_chain(c, pk, ep_out, tmp, prep_of(c, 1), d1q, 1, ws);          // (cannot happen with these buffers; kept for safety)
+        trace_steps(c, last, ref(c->d_last_res, G, 0), tmp, 0, LOGN, 1, ws);          // ram.rs:457 / 540
+    }
     if (gated) {   // behind a gate that opens when the trace chain's launch is placed (no event on the main stream); host order is irrelevant
         const unsigned seq = c->tail_launches != tl0 ? c->tail_seq : 0;                // 0: no such launch after all -> event fork
         for (int ci = c->n2 - 1; ci >= 0; ci--) precompute_inverse(c, addr, ci, ci == c->n2 - 1, seq);
@@ -171,6 +185,7 @@ int read_impl(fheram_ctx* c, const fheram_addr* addr, bool prepare_write) {
 // Stage 1 (root / unsharded): write_first_step on the top of the tree and, for n2 == 2, the inverse
 // coordinate-1 products: leaves the un-rotated ct_lo of every sub-RAM in d_part.
 int write_top(fheram_ctx* c, const fheram_addr* addr) {
+    c->wide = true;             // (everything a write enqueues runs behind read_prepare_write's trace chain, whose placement releases the gate wave)
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     const int ws = c->ws;
@@ -207,6 +222,7 @@ int write_top(fheram_ctx* c, const fheram_addr* addr) {
 // so that it fills the CUs the latency-bound stage 1 (a chain of word_size-ciphertext launches)
 // leaves idle.
 void write_side_begin(fheram_ctx* c, const fheram_addr* addr) {
+    c->wide = true;
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     hipEventRecord(c->ev_fork, c->stream);            // everything before this write (rows after rpw)
@@ -241,6 +257,7 @@ void write_side_abort(fheram_ctx* c) {
 }
 // Stage 2 (every shard): write_mid_step on the local rows given ct_lo (in d_part), then write_last_step.
 int write_rows(fheram_ctx* c, const fheram_addr* addr) {
+    c->wide = true;
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     const int ws = c->ws, R = (int)c->rows;

@@ -39,7 +39,7 @@ enum fheram_status {
     FHERAM_ERR_UNSUPPORTED = 5,   /* parameter set the kernels are not built for             */
     FHERAM_ERR_RANGE = 6,         /* a limb is not normalised                                */
     FHERAM_ERR_DEVICE = 7,        /* HIP runtime error                                       */
-    FHERAM_ERR_PRECISION = 8      /* the FP64 round-off monitor saw |x - rint(x)| > 1/4 (no reference counterpart: Poulpy's FFT64
+    FHERAM_ERR_PRECISION = 8      /* the FP64 round-off monitor saw |x - rint(x)| > 3/8 (no reference counterpart: Poulpy's FFT64
                                      backend, examples/fhe-ram.rs:3-7, rounds unchecked)     */
 };
 
@@ -119,11 +119,12 @@ int fheram_sync(fheram_ctx* ctx);
 /* ---- The exactness contract, checked.  The reference multiplies with Poulpy's FFT64 backend and rounds (examples/fhe-ram.rs:3-7);
  * so does csrc/fft_dev.hpp: the rounded output of an inverse transform is the exact integer only while the accumulated FP64
  * round-off stays below 1/2.  No a-priori bound below 1/2 is known for six accumulated terms of extreme limbs (measured worst
- * case found by search 0.219: DESIGN.md §2), so every rounding on the path reports |x - rint(x)|, every coefficient, to a
- * per-context monitor (fheram_config.monitor, on by default; 0.3 % of a step).
+ * case found by search 0.25: DESIGN.md §2), so every rounding on the path reports |x - rint(x)| to a per-context monitor
+ * (fheram_config.monitor: one coefficient per thread and transform by default, every coefficient under `safe`).
  *   fheram_roundoff_max: waits for the context's streams; *max_out = the largest round-off seen since creation / the last reset;
- *                        returns FHERAM_ERR_PRECISION if it exceeds 1/4 (max_out is still written).
- *   Once a round-off above 1/4 was seen, every call that waits for the device (fheram_sync, the downloads of fheram_read /
+ *                        returns FHERAM_ERR_PRECISION if it exceeds 3/8 — halfway between the largest round-off a search over
+ *                        extreme operands has produced (1/4, tools/fft_search.hip) and failure (1/2); max_out is still written.
+ *   Once a round-off above 3/8 was seen, every call that waits for the device (fheram_sync, the downloads of fheram_read /
  *   fheram_read_prepare_write / fheram_result_map / fheram_ram_download, fheram_timer_end) returns FHERAM_ERR_PRECISION until
  *   fheram_roundoff_reset.  No reference counterpart. */
 int fheram_roundoff_max(fheram_ctx* ctx, double* max_out);
@@ -144,8 +145,8 @@ int fheram_ctx_create_sharded(const fheram_params* params, int device, int shard
 /* Execution switches of a context: which decomposition / hand-over form the launchers of csrc/launch.hpp choose.  Every setting
  * computes the same results (tests/test_gpu_parity.py and test_gpu_golden.py force each one); the defaults are the fastest
  * measured forms.  fheram_config_default() fills the library defaults and then applies the FHERAM_* environment overrides of
- * the same names (FHERAM_LIMB_SPLIT, _FINE_SPLIT, _MEMO, _PRE_INV, _TAIL, _MID, _CHAIN, _CHAIN_Y, _PAIR_Z, _FUSE, _GRAPH,
- * _SAFE, _NCO); fheram_ctx_create / _sharded use exactly that.  No reference counterpart (the reference has one code path). */
+ * the same names (FHERAM_LIMB_SPLIT, _FINE_SPLIT, _MEMO, _PRE_INV, _TAIL, _TAIL_EP, _MID, _CHAIN, _CHAIN_Y, _PAIR_Z, _FUSE, _GRAPH,
+ * _SAFE, _NCO, _MONITOR); fheram_ctx_create / _sharded use exactly that.  No reference counterpart (the reference has one code path). */
 typedef struct fheram_config {
     int32_t limb_split;   /* 1: limb-parallel launches for batches far smaller than the chip */
     int32_t fine_split;   /* 1: one forward + one inverse transform per workgroup for <= 10 key-switches / <= 5 products */
@@ -162,7 +163,8 @@ typedef struct fheram_config {
     int32_t graph;        /* 1: replay each op's launch sequence from a hipGraph */
     int32_t safe;         /* 1: no in-kernel hand-offs between workgroups, no gate wave: stays inside the HIP memory model */
     int32_t nco;          /* output columns per workgroup: 1, 2, or 0 = chosen per launch */
-    int32_t monitor;      /* round-off monitor (fheram_roundoff_max): 1 (default) every rounding of an inverse transform reports its round-off; 0 nothing is reported or checked */
+    int32_t tail_ep;      /* 1 (default): coordinate 1's external products (>= 2 digits) run inside that launch, in front of the trace steps; 0: launches of their own */
+    int32_t monitor;      /* round-off monitor (fheram_roundoff_max): 1 (default) every rounding of an inverse transform reports one of the thread's eight coefficients (which one differs between call sites); 2 all eight (what `safe` selects); 0 nothing is reported or checked */
     int32_t reserved;     /* must be 0 (a later version / size field): fheram_ctx_create_cfg refuses anything else */
 } fheram_config;
 /* ALWAYS start from fheram_config_default(): a zero-initialised struct is a valid configuration, but it selects every slow

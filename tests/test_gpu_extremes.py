@@ -8,7 +8,7 @@ ep_step_r / the streamed ks_trace_l, where 75 % of the arithmetic runs; the cohe
 and maximise the sums (6 * 4096 * 2^32), i.e. they are where the FP64 round-off of the FFT64 arithmetic is largest
 (tests/test_gpu_fft.py pins it at the transform level: 0.125).  Bit-exactness here = the rounded results are still the exact
 integers in the kernels' own summation order (one product per hook of the hooked transforms); the round-off monitor
-(fheram_roundoff_max) must agree that they were.  The inputs are not valid ciphertexts: nothing decrypts,
+(fheram_roundoff_max, every coefficient) must agree that they were.  The inputs are not valid ciphertexts: nothing decrypts,
 everything compares."""
 import numpy as np
 import pytest
@@ -90,8 +90,8 @@ def test_extreme_limbs_through_the_chain_kernels(po, pat, log_max_addr):
            "words": _fill(words_r, (ws, p.glwe_len()), rng)}
     want = _oracle_flow(po, max_addr, ws, inp, _threads())
     worst = 0.0
-    for cfg in ({}, {"chain_y": 0}, {"fuse": 0}):
-        ram = pkg.Ram(p, config=cfg or None)
+    for cfg in ({"monitor": 2}, {"monitor": 2, "chain_y": 0}, {"monitor": 2, "fuse": 0}):
+        ram = pkg.Ram(p, config=cfg)
         keys = pkg.EvaluationKeysPrepared(pkg.galois_elements(12), list(inp["atk"]), inp["atk_inv"], inp["tsk"])
         addr = pkg.Address(p, list(inp["addr"]))
         ram.load_encrypted(inp["rows"])

@@ -69,10 +69,10 @@ def test_hip_flow_matches_committed_digests(po, key):
 @pytest.mark.parametrize("env", [{"FHERAM_LIMB_SPLIT": "0", "FHERAM_NCO": "1"}, {"FHERAM_LIMB_SPLIT": "0", "FHERAM_NCO": "2", "FHERAM_CHAIN": "0"},
                                  {"FHERAM_FINE_SPLIT": "0"}, {"FHERAM_MEMO": "0"}, {"FHERAM_GRAPH": "1"}, {"FHERAM_TAIL": "2"},
                                  {"FHERAM_CHAIN_Y": "0"}, {"FHERAM_PRE_INV": "0"}, {"FHERAM_SAFE": "1"},
-                                 {"FHERAM_FUSE": "0", "FHERAM_PAIR_Z": "0"}],
+                                 {"FHERAM_FUSE": "0", "FHERAM_PAIR_Z": "0"}, {"FHERAM_TAIL_EP": "0"}, {"FHERAM_TAIL_EP": "0", "FHERAM_TAIL": "2"}],
                          ids=["column-split", "fused-unchained", "limb-parallel", "write-recomputes", "hipgraph-replay", "tail-gives-up",
                               "limb-handover", "write-inverts", "safe-no-inkernel-handoffs",
-                              "row-chains-as-separate-launches-old-combine"])
+                              "row-chains-as-separate-launches-old-combine", "coordinate-1-products-as-launches", "trace-only-tail-gives-up"])
 def test_forced_decompositions_reproduce_the_2_18_digests(env):
     """The launch heuristics are tuned on one chip shape and one RAM size; every alternative decomposition is forced at 2^14
     in test_gpu_parity.py — and here at the FULL size of BASELINE.json configs[2..3] (256 ciphertexts per round: the fused chain

@@ -114,12 +114,12 @@ def test_config_defaults_and_environment_overrides(monkeypatch):
     L.fheram_config_default(C.byref(cfg))
     got = {f: getattr(cfg, f) for f in _CONFIG_FIELDS}
     assert got == {"limb_split": 1, "fine_split": 1, "memo": 1, "pre_inv": 1, "tail": 1, "tail_test": 0, "mid": 2, "mid_test": 0, "chain": 1,
-                   "chain_y": 3, "pair_z": 1, "fuse": 1, "graph": 0, "safe": 0, "nco": 0, "monitor": 1, "reserved": 0}
+                   "chain_y": 3, "pair_z": 1, "fuse": 1, "graph": 0, "safe": 0, "nco": 0, "tail_ep": 1, "monitor": 1, "reserved": 0}
     for name, val, field, want in (("FHERAM_SAFE", "1", "safe", 1), ("FHERAM_CHAIN_Y", "0", "chain_y", 0), ("FHERAM_TAIL", "2", "tail_test", 1),
                                    ("FHERAM_TAIL", "0", "tail", 0), ("FHERAM_MID", "2", "mid_test", 1), ("FHERAM_MID", "1", "mid", 1),
                                    ("FHERAM_NCO", "2", "nco", 2), ("FHERAM_PRE_INV", "2", "pre_inv", 2), ("FHERAM_GRAPH", "1", "graph", 1),
                                    ("FHERAM_FUSE", "0", "fuse", 0), ("FHERAM_MEMO", "0", "memo", 0), ("FHERAM_LIMB_SPLIT", "0", "limb_split", 0),
-                                   ("FHERAM_MONITOR", "0", "monitor", 0)):
+                                   ("FHERAM_MONITOR", "0", "monitor", 0), ("FHERAM_MONITOR", "2", "monitor", 2), ("FHERAM_TAIL_EP", "0", "tail_ep", 0)):
         monkeypatch.setenv(name, val)
         L.fheram_config_default(C.byref(cfg))
         assert getattr(cfg, field) == want, (name, val)
