@@ -1,6 +1,6 @@
 #!/bin/bash
 # First contact with a multi-GPU node as ONE command (BASELINE.json configs[4]: MAX_ADDR = 2^21, rows sharded over the GPUs).
-# The last column compares with the one-GPU prediction of tools/scaling_model.py (profiles/r05_scaling_model.json; rehearsals on one
+# The last column compares with the one-GPU prediction of tools/scaling_model.py (profiles/r06_scaling_model.json; rehearsals on one
 # GPU time-share it, so the ratio means something on a multi-GPU node only).
 # For N in 1 2 4 8 (or $NS): the committed 2^21 digests through the native group (fheram_group_*, one process) and through
 # one process per GPU over RCCL, then bench.py in both modes; prints a table.  Nothing here needs /root/reference.
@@ -20,7 +20,7 @@ PORT=29580
 RANKS_MAX=${RANKS_MAX:-64}     # the one-process-per-GPU legs are skipped above this N (a 1-GPU rehearsal box admits 6 GPU processes)
 fail=0
 out=$(mktemp -d)
-printf "%-3s %-22s %-10s %-12s %-10s %-10s %-10s %s\n" N mode digests "RAM ops/s" read_ms rpw_ms write_ms "measured / predicted (profiles/r05_scaling_model.json)"
+printf "%-3s %-22s %-10s %-12s %-10s %-10s %-10s %s\n" N mode digests "RAM ops/s" read_ms rpw_ms write_ms "measured / predicted (profiles/r06_scaling_model.json)"
 for n in $NS; do
   # --- one process, n devices (native group)
   python tests/scale_digest_worker.py --mode group --n $n --log-max-addr $LOG $EXTRA > $out/gd_$n.json 2> $out/gd_$n.err; gd=$?
@@ -31,7 +31,7 @@ f, n, mode, gd, gb, log = sys.argv[1:7]
 def predicted(n, log):
     try:
         import os
-        m = json.load(open(os.path.join("profiles", "r05_scaling_model.json")))
+        m = json.load(open(os.path.join("profiles", "r06_scaling_model.json")))
         for r in m["rows"]:
             if r["mode"] == "strong" and r["total_log_max_addr"] == int(log) and r["gpus"] == int(n):
                 return r["ram_ops_s"]
@@ -65,7 +65,7 @@ f, n, mode, rd, rb, be, log = sys.argv[1:8]
 def predicted(n, log):
     try:
         import os
-        m = json.load(open(os.path.join("profiles", "r05_scaling_model.json")))
+        m = json.load(open(os.path.join("profiles", "r06_scaling_model.json")))
         for r in m["rows"]:
             if r["mode"] == "strong" and r["total_log_max_addr"] == int(log) and r["gpus"] == int(n):
                 return r["ram_ops_s"]

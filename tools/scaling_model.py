@@ -14,7 +14,7 @@ copies of < 4 MB over xGMI; XCHG_US each, default 25 us — the one number this 
   RAM ops/s = 2 / (read + rpw + write)
 
 Strong scaling: TOTAL fixed (2^21: BASELINE.json configs[4]).  Weak scaling: 2^18 per GPU (TOTAL = G * 2^18), efficiency T(1)/T(G).
-usage: python tools/scaling_model.py [--xchg-us 25] > profiles/r05_scaling_model.txt
+usage: python tools/scaling_model.py [--xchg-us 25] > profiles/r06_scaling_model.txt
 `tools/scale_check.sh` prints measured / predicted against the committed file on a multi-GPU node."""
 import argparse
 import json
