@@ -129,18 +129,23 @@ def pmc_profile():
 
 
 def pmc_traffic(kernel_prefix):
-    """HBM-side bytes per launch (read + written) of the kernel whose name starts with `kernel_prefix`, from the committed PMC
-    profile of this command (tools/pmc_hbm.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE calibrated);
-    None if absent"""
+    """HBM-side bytes per launch (read + written) of the kernel(s) whose name starts with `kernel_prefix` (a string or a tuple of them:
+    the two register-budget variants of a chain kernel are one launch class), from the committed PMC profile of this command
+    (tools/pmc_hbm.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE calibrated); launches of the same kernel on
+    a token grid (the predicated fallback behind the trace tail) are left out; launch-weighted mean over the rest; None if absent"""
     prof = pmc_profile()
     if not prof:
         return None
-    best = None
+    prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
+    tot = n = 0
     for name, e in prof.get("kernels", {}).items():
-        if name.startswith(kernel_prefix) and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e:
-            if best is None or e["launches"] > best["launches"]:
-                best = e
-    return None if best is None else best["read_bytes_per_launch"] + best["write_bytes_per_launch"]
+        if name.startswith(prefixes) and "read_bytes_per_launch" in e and "write_bytes_per_launch" in e:
+            b = e["read_bytes_per_launch"] + e["write_bytes_per_launch"]
+            if b < (1 << 20):
+                continue
+            tot += b * e["launches"]
+            n += e["launches"]
+    return tot / n if n else None
 
 
 def pmc_valu_busy(kernel_label):
@@ -757,14 +762,14 @@ def main():
         sk = s_evk
         alg_ks = alg_flop_per_keyswitch(s_evk)
         table = [
-            entry(f"k_read_chain<{sk},4>", f"a row's {d0} products of coordinate 0 + its {L0r} alone packer levels as ONE launch, one workgroup per row (ram.rs:429-435,502-514)",
-                  rc["ms"], rc["launches"], rc["blocks"] * (d0 * FP64_PER_EP + L0r * fp64_per_ks), f"fk::k_read_chain<{sk}, 4>", d0 + L0r,
+            entry(f"k_read_chain<{sk},4> / k_read_chain_w<{sk},4>", f"a row's {d0} products of coordinate 0 + its {L0r} alone packer levels as ONE launch, one workgroup per row (ram.rs:429-435,502-514)",
+                  rc["ms"], rc["launches"], rc["blocks"] * (d0 * FP64_PER_EP + L0r * fp64_per_ks), (f"fk::k_read_chain<{sk}, 4>", f"fk::k_read_chain_w<{sk}, 4>"), d0 + L0r,
                   alg=rc["blocks"] * (d0 * ALG_FLOP_PER_EP + L0r * alg_ks)),
             entry(f"k_write_chain<{sk},4>", f"write_mid_step's 12 trace steps of ct_lo X^-row + normalize(ct_hi - trace(ct_hi) + .) + write_last_step's {d0} products as ONE launch (ram.rs:612-646)",
                   wc["ms"], wc["launches"], wc["blocks"] * (d0 * FP64_PER_EP + 12 * fp64_per_ks), f"fk::k_write_chain<{sk}, 4>", d0 + 12,
                   alg=wc["blocks"] * (d0 * ALG_FLOP_PER_EP + 12 * alg_ks)),
             entry(f"k_keyswitch_chain<3,{sk},3,{forms.get('chain_y', 3)}>", "pure trace chains, one workgroup per ciphertext (at 2^18: trace(ct_hi) steps 6..11 on the write's side stream, ram.rs:616)",
-                  pure_ms, pc["launches"], pc["blocks"] * fp64_per_ks, f"fk::k_keyswitch_chain<3, {sk}, 3, {forms.get('chain_y', 3)}>",
+                  pure_ms, pc["launches"], pc["blocks"] * fp64_per_ks, (f"fk::k_keyswitch_chain<3, {sk}, 3, {forms.get('chain_y', 3)}>", f"fk::k_keyswitch_chain_w<3, {sk}, 3, {forms.get('chain_y', 3)}>"),
                   (pc["blocks"] / pc["launches"] / max(1.0, classes["keyswitch_fused"]["blocks"] / max(1, classes["keyswitch_fused"]["launches"]))) if pc["launches"] else None,
                   alg=pc["blocks"] * alg_ks),
             entry(f"k_trace_tail<3,{sk},3>", "GLWE::trace on the word_size results at the end of a read: 12 dependent steps as one launch with in-kernel hand-offs (ram.rs:457,540)",
@@ -795,7 +800,7 @@ def main():
         if table:
             dom = dict(table[0])
             ratio = None
-            if dom["kernel"].startswith("k_read_chain"):
+            if dom["kernel"].startswith("k_read_chain"):   # (both register budgets: one launch class)
                 ratio = (d0 * R04_FP64_PER_EP + L0r * R04_FP64_PER_KS) / (d0 * FP64_PER_EP + L0r * FP64_PER_KS) if s_evk == 4 else None
                 n_ep, n_ks = d0, L0r
             elif dom["kernel"].startswith("k_write_chain"):
