@@ -121,6 +121,15 @@ public:
     ~Ram() { if (ctx_) fheram_ctx_destroy(ctx_); }
 
     size_t glwe_len() const { return fheram_glwe_len(ctx_); }
+    // The exactness contract of the FFT64 arithmetic, checked (include/fheram.h: fheram_roundoff_max): the largest |x - rint(x)| any rounding
+    // has seen on this context; throws Error(FHERAM_ERR_PRECISION) once it has passed 3/8, like every call that waits for the device.
+    double roundoff_max() {
+        double m = 0.0;
+        const int rc = fheram_roundoff_max(ctx_, &m);
+        if (rc != FHERAM_OK) throw Error(rc, fheram_last_error(ctx_));
+        return m;
+    }
+    void roundoff_reset() { const int rc = fheram_roundoff_reset(ctx_); if (rc != FHERAM_OK) throw Error(rc, fheram_last_error(ctx_)); }
 
     // Ram::encrypt_sk hand-over (ram.rs:129-167): rows = [word_size][rows][GLWE], already encrypted.
     void load_encrypted(const std::vector<int64_t>& rows) {
