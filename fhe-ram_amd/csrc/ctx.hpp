@@ -146,6 +146,14 @@ struct fheram_ctx {
     hipEvent_t ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};   // a precompute of coordinate ci has been enqueued on the side stream and no write has consumed / overwritten it
     hipEvent_t ev_wdone = nullptr;          // recorded at the end of every write (main stream): the next precompute waits for it
+    // recorded on the main stream where a read_prepare_write STARTS (free there: nothing of the op has been enqueued yet); its gate wave waits for
+    // it on the side stream.  A host that enqueues ops without waiting for them is ahead of the device: without this the gate wave could be
+    // parked while the PREVIOUS op's 256-register chain launch is still being placed, and cost that launch a second round on one CU.
+    // Only needed while a 256-register launch of an earlier op may still be waiting for its CUs: wide_unsynced = such a launch has been enqueued
+    // and the host has not waited for the stream since (a host that waits for every op — the reference's calling pattern — never pays the record).
+    hipEvent_t ev_opstart = nullptr;
+    bool opstart_valid = false;
+    bool wide_unsynced = false;
     bool wdone_pending = false;
     bool memo_top = false;
     int memo_alone = 0;

@@ -257,6 +257,7 @@ int fheram_ctx_create_cfg(const fheram_params* p, int device, int shard, int n_s
     CCHK(hipMalloc(&c->d_ggsw_inv, (size_t)c->n_digits * fheram_ctx::GGSW * sizeof(int32_t)));
     for (int i = 0; i < 2; i++) CCHK(hipEventCreateWithFlags(&c->ev_inv[i], hipEventDisableTiming));
     CCHK(hipEventCreateWithFlags(&c->ev_wdone, hipEventDisableTiming));
+    CCHK(hipEventCreateWithFlags(&c->ev_opstart, hipEventDisableTiming));
     CCHK(hipMalloc(&c->d_tail_sync, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     CCHK(hipMemset(c->d_tail_sync, 0, (size_t)(TAIL_GROUPS + 1) * 32 * sizeof(unsigned)));
     for (int i = 0; i < 2; i++) {
@@ -288,6 +289,7 @@ void fheram_ctx_destroy(fheram_ctx* c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     for (int i = 0; i < 2; i++) if (c->ev_inv[i]) hipEventDestroy(c->ev_inv[i]);
     if (c->ev_wdone) hipEventDestroy(c->ev_wdone);
+    if (c->ev_opstart) hipEventDestroy(c->ev_opstart);
     if (c->ev_xout) hipEventDestroy(c->ev_xout);
     if (c->ev_xin) hipEventDestroy(c->ev_xin);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -421,6 +423,7 @@ int fheram_result_map(fheram_ctx* c, const int64_t** out) {
                        reinterpret_cast<long long*>(c->d_h_res), n4, reinterpret_cast<const long long*>(c->d_tw + N));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    c->wide_unsynced = false;
     *out = c->h_res;
     {   // the monitor's maximum as it stood when the result was exported (the export kernel copies it behind the result)
         double m;
@@ -442,6 +445,7 @@ int fheram_sync(fheram_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    c->wide_unsynced = false;
     return check_precision(c);
 }
 int fheram_roundoff_max(fheram_ctx* c, double* max_out) {
@@ -748,6 +752,7 @@ int fheram_timer_end(fheram_ctx* c, float* ms) {
     HIPCHK(c, hipEventRecord(c->t1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->t1));
     HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    c->wide_unsynced = false;   // (t1 was recorded behind everything enqueued on the main stream)
     return check_precision(c);
 }
 int fheram_profile_enable(fheram_ctx* c, int on) {

@@ -251,11 +251,11 @@ void launch_trace_chain(fheram_ctx* c, GlweRef src, const GlweRef (&b)[2], int s
     for (int i = 0; i < n; i++) { ca.key[i] = trace_key(c, start + i); ca.ginv[i] = galois_inv_mod(galois_mod(c->gal[start + i])); }
     const int yf = n >= 2 ? c->chain_y : 0;   // intermediates handed over as Y = ceil(A/2) through LDS and registers (ks_trace_l); 0: int32 limbs (ks_run)
     if (c->s_evk == 5) {
-        if (yf && c->wide) hipLaunchKernelGGL((k_keyswitch_chain_w<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf && c->wide) { c->wide_unsynced = true; hipLaunchKernelGGL((k_keyswitch_chain_w<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca); }
         else if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 5, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     } else {
-        if (yf && c->wide) hipLaunchKernelGGL((k_keyswitch_chain_w<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
+        if (yf && c->wide) { c->wide_unsynced = true; hipLaunchKernelGGL((k_keyswitch_chain_w<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca); }
         else if (yf) hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
         else hipLaunchKernelGGL((k_keyswitch_chain<3, 4, 3>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ca);
     }
@@ -287,10 +287,10 @@ void launch_read_chain(fheram_ctx* c, GlweRef src, const GlweRef* ep_store, Glwe
     ra.ks.buf[0] = ra.ks.buf[1] = dst;                            // only the last step stores
     ra.hi = dst; ra.trhi = dst;
     if (c->s_evk == 5) {
-        if (c->wide) hipLaunchKernelGGL((k_read_chain_w<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+        if (c->wide) { c->wide_unsynced = true; hipLaunchKernelGGL((k_read_chain_w<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra); }
         else hipLaunchKernelGGL((k_read_chain<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
     } else {
-        if (c->wide) hipLaunchKernelGGL((k_read_chain_w<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
+        if (c->wide) { c->wide_unsynced = true; hipLaunchKernelGGL((k_read_chain_w<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra); }
         else hipLaunchKernelGGL((k_read_chain<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
     }
 }
@@ -303,6 +303,7 @@ void launch_write_chain(fheram_ctx* c, GlweRef src, int rot_mul, int rot_base, G
     ra.ks.buf[0] = ra.ks.buf[1] = data;                           // (no trace step stores)
     ra.hi = data; ra.trhi = trhi;
     ra.ep.src = data; ra.ep.buf[0] = ra.ep.buf[1] = data;         // only the last product stores: in place on the rows
+    c->wide_unsynced = true;                                      // (k_write_chain takes the whole register file)
     if (c->s_evk == 5) hipLaunchKernelGGL((k_write_chain<5, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
     else hipLaunchKernelGGL((k_write_chain<4, 4>), dim3(gx, gy, 1), dim3(T), LDS_BYTES, c->cur, ra);
 }
@@ -504,6 +505,7 @@ void precompute_inverse(fheram_ctx* c, const fheram_addr* addr, int ci, bool for
         c->wdone_pending = false;
     }
     if (fork && gate_seq) {
+        if (c->opstart_valid) { hipStreamWaitEvent(c->stream2, c->ev_opstart, 0); c->opstart_valid = false; }   // not before the op that parks it has started
         hipLaunchKernelGGL(k_tail_gate, dim3(1), dim3(64), 0, c->stream2, c->d_tail_sync + TAIL_GROUPS * 32 + 2, gate_seq);
     } else if (fork) {
         hipEventRecord(c->ev_fork, c->stream);

@@ -62,6 +62,10 @@ int check_common(fheram_ctx* c, const fheram_addr* addr) {
 // indexed by sub-RAM); to_part also copies it into d_part (the buffer a sharded RAM exchanges).
 int read_local(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, GlweRef* packed_out, bool to_part) {
     c->wide = !prepare_write;   // read_prepare_write parks the gate wave beside its launches (read_top): its chain kernels keep a wave slot free
+    if (prepare_write && c->pre_inv == 1 && !capturing(c) && c->wide_unsynced) {   // the gate wave may not be parked before this op's own launches start (ctx.hpp: ev_opstart)
+        hipEventRecord(c->ev_opstart, c->stream);
+        c->opstart_valid = true;
+    }
     const long G = (long)fheram_ctx::GLWE;
     const long sy = (long)c->rows * G;
     const int ws = c->ws;
@@ -163,6 +167,10 @@ int read_top(fheram_ctx* c, const fheram_addr* addr, bool prepare_write, int32_t
     else {
         if (fuse_ep) ep_chain(c, pk, ep_out, tmp, prep_of(c, 1), d1q, 1, ws);          // (cannot happen with these buffers; kept for safety)
         trace_steps(c, last, ref(c->d_last_res, G, 0), tmp, 0, LOGN, 1, ws);          // ram.rs:457 / 540
+    }
+    if (gated && !c->opstart_valid && c->wide_unsynced) {   // (a root's read_finish: no read_local of this op ran on this context)
+        hipEventRecord(c->ev_opstart, c->stream);
+        c->opstart_valid = true;
     }
     if (gated) {   // behind a gate that opens when the trace chain's launch is placed (no event on the main stream); host order is irrelevant
         const unsigned seq = c->tail_launches != tl0 ? c->tail_seq : 0;                // 0: no such launch after all -> event fork
