@@ -10,7 +10,9 @@
 //   k_read_chain / k_write_chain (round 4)  a row's product chain and trace chain (ram.rs:429-435,502-514 / 612-646) as one
 //                  launch each: ep_step_r + ks_trace_l, the normalisation in closed form, steps handed over in LDS / registers
 //   k_keyswitch_chain / k_ext_product_chain(_r)  the same chains on their own; k_pair_z  the column-split packer combine
-//   k_trace_tail / k_chain_mid  dependent chains on few ciphertexts with in-kernel hand-offs between workgroups of one XCD
+//   k_trace_tail / k_chain_mid  dependent chains on few ciphertexts with in-kernel hand-offs between workgroups of one XCD (k_trace_tail: coordinate 1's
+//                  products in front of the trace, round 6)
+//   chain_kernels.inc           k_keyswitch_chain / k_read_chain in two register budgets (included twice: 240 registers beside the gate wave, 256 otherwise)
 //
 // Device GLWE layout: int32 [limb][col][N] (the host's int64 layout narrowed; limbs are
 // normalised to 17 bits so nothing is lost).  Prepared operands: double, transform domain,
@@ -1930,6 +1932,11 @@ __global__ __launch_bounds__(T, T / 256) __attribute__((amdgpu_num_vgpr(FK_WIDE_
 // co-resident because another context holds the CUs, wrong placement) raises the abort word to this launch's
 // generation and leaves; the fused chain launch enqueued right behind (k_keyswitch_chain, predicated on that word)
 // then redoes the chain from the untouched source.  Results are the same either way (same per-coefficient arithmetic).
+// Round 6: coordinate 1's external products (ram.rs:454 / 525-527: the steps in front of that trace, two digits or more) run in the SAME launch
+// as product steps — fine split as k_ext_product_fine (member (co, j, r) of the first 24: digit r of both columns, two operand polynomials, one
+// inverse transform) and the products' own normalisation phase; the launch enqueued behind is then the predicated fused row chain (k_read_chain:
+// products + trace steps on one workgroup per ciphertext).  Measured and removed the same round (profiles/r06_experiments.txt 3, 7): ONE hand-off per
+// step with the closed-form contributions added by L2 atomics, and the last pair levels of the packing tree as steps of this launch.
 //   grid (8 * 2*SK*SX): group g = (b - xoff) % 8 = ciphertext (x = g % gx, y = g / gx), member m = b / 8 = ((co*SK + (SK-1-j))*SX + r)
 //   sync: [group][32] words: arrivals, leavers, XCC mask;  sync[8*32] = abort generation
 // ---------------------------------------------------------------------------------------
