@@ -140,8 +140,8 @@ def test_precision_error_is_raised_and_sticky(monitor):
 
 def test_searched_worst_pattern_is_pinned(ram):
     """tests/golden/fft_worst_pattern.bin: the operands with the largest round-off that tools/fft_search.hip has found (a hill climb
-    over "every coefficient of both operands of all six terms at -2^16 or at 2^16 - 1", 21 * 10^6 evaluations in seven
-    runs, three of which reached it): 0.25 — twice the hand-picked worst case, one bit below failure.  Pinned: the raw sums are still within 0.3 of the exact
+    over "every coefficient of both operands of all six terms at -2^16 or at 2^16 - 1", 36.6 * 10^6 evaluations in eleven
+    runs, five of which reached it): 0.25 — twice the hand-picked worst case, one bit below failure.  Pinned: the raw sums are still within 0.3 of the exact
     integers and round to them; the monitor's limit (3/8) sits between this and 1/2."""
     import os
     bits = np.unpackbits(np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fft_worst_pattern.bin"), dtype=np.uint8), bitorder="little")
